@@ -1,0 +1,258 @@
+"""ctypes front end of the CPU oracle (oracle/mnw_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; the product package (minnow_amd) never imports it.
+
+Each wrapper names the reference function it restates (see mnw_oracle.h for file:line).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmnw_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mnw_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libmnw_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        i64, u64, p, f32, dbl, ci = C.c_int64, C.c_uint64, C.c_void_p, C.c_float, C.c_double, C.c_int
+        sigs = {
+            "mnwo_precision_needed": (i64, [u64]),
+            "mnwo_go_log2": (dbl, [dbl]),
+            "mnwo_array_bytes": (i64, [i64, i64]),
+            "mnwo_pack": (ci, [ci, p, i64, p, i64]),
+            "mnwo_unpack": (ci, [ci, p, i64, p]),
+            "mnwo_pack_fast": (ci, [ci, p, i64, p, i64]),
+            "mnwo_unpack_fast": (ci, [ci, p, i64, p]),
+            "mnwo_bits": (i64, [p, i64]),
+            "mnwo_int64_min": (i64, [p, i64]),
+            "mnwo_bound": (None, [p, i64, i64, i64]),
+            "mnwo_periodic_min": (i64, [p, i64, i64]),
+            "mnwo_periodic_distance": (i64, [i64, i64, i64]),
+            "mnwo_float_group_pixels": (i64, [f32, f32, f32]),
+            "mnwo_int_encode": (ci, [p, i64, p, p, p, p, p, ci]),
+            "mnwo_int_decode": (ci, [p, i64, i64, i64, p, p, ci]),
+            "mnwo_float_encode": (ci, [p, i64, f32, f32, i64, ci, p, p, p, p, p, p, ci]),
+            "mnwo_quantize": (None, [p, i64, f32, f32, i64, p]),
+            "mnwo_float_decode": (ci, [p, i64, i64, f32, f32, i64, ci, p, i64, p, p, p, ci]),
+            "mnwo_float_decode_q": (ci, [p, i64, i64, i64, ci, i64, p, p, ci]),
+            "mnwo_dither_u01": (dbl, [u64, u64, u64]),
+            "mnwo_dither_fill": (None, [u64, u64, i64, p]),
+            "mnwo_tail_array_encode": (i64, [p, i64, p]),
+            "mnwo_tail_array_decode": (i64, [p, i64, p]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def precision_needed(mx):
+    """bit.PrecisionNeeded"""
+    return int(lib().mnwo_precision_needed(C.c_uint64(int(mx) & (2**64 - 1))))
+
+
+def go_log2(x):
+    return float(lib().mnwo_go_log2(float(x)))
+
+
+def array_bytes(bits, length):
+    """bit.ArrayBytes"""
+    return int(lib().mnwo_array_bytes(int(bits), int(length)))
+
+
+def pack(bits, x, literal=True):
+    """bit.NewArray(bits, x).Data"""
+    x = _c(x, np.uint64)
+    n = x.size
+    out = np.empty(array_bytes(bits, n), dtype=np.uint8)
+    fn = lib().mnwo_pack if literal else lib().mnwo_pack_fast
+    rc = fn(int(bits), _ptr(x), n, _ptr(out), out.size)
+    if rc:
+        raise ValueError("oracle pack failed rc=%d" % rc)
+    return out
+
+
+def unpack(bits, data, n, literal=True):
+    """(*bit.Array).Slice"""
+    data = _c(data, np.uint8)
+    out = np.empty(n, dtype=np.uint64)
+    # the literal decoder reads one byte past a 64-bit element's last byte only when that
+    # byte exists in Go's array; pad so the C side never reads outside the buffer
+    padded = np.concatenate([data, np.zeros(16, np.uint8)])
+    fn = lib().mnwo_unpack if literal else lib().mnwo_unpack_fast
+    if not literal:
+        padded = data if data.size else np.zeros(1, np.uint8)
+    rc = fn(int(bits), _ptr(padded), int(n), _ptr(out))
+    if rc:
+        raise ValueError("oracle unpack failed rc=%d" % rc)
+    return out
+
+
+def bits_needed(x):
+    """bit.ArrayBuffer.Bits"""
+    x = _c(x, np.uint64)
+    return int(lib().mnwo_bits(_ptr(x), x.size))
+
+
+def int64_min(x):
+    x = _c(x, np.int64)
+    return int(lib().mnwo_int64_min(_ptr(x), x.size))
+
+
+def bound(x, mn, pixels):
+    x = np.array(x, dtype=np.int64)
+    lib().mnwo_bound(_ptr(x), x.size, int(mn), int(pixels))
+    return x
+
+
+def periodic_min(x, pixels):
+    x = _c(x, np.int64)
+    return int(lib().mnwo_periodic_min(_ptr(x), x.size, int(pixels)))
+
+
+def float_group_pixels(low, high, dx):
+    """Writer.FloatGroup's pixels derivation (writer.go:73)"""
+    return int(lib().mnwo_float_group_pixels(float(np.float32(low)), float(np.float32(high)),
+                                             float(np.float32(dx))))
+
+
+def int_encode(x, literal=True):
+    """intGroup.writeData -> (min, bits, stream bytes)"""
+    x = _c(x, np.int64)
+    n = x.size
+    out = np.zeros(8 * n + 8, dtype=np.uint8)
+    scratch = np.empty(max(n, 1), dtype=np.uint64)
+    mn, bits, olen = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib().mnwo_int_encode(_ptr(x), n, C.byref(mn), C.byref(bits), _ptr(out),
+                               C.byref(olen), _ptr(scratch), int(literal))
+    if rc:
+        raise ValueError("oracle int_encode failed rc=%d (bits=%d)" % (rc, bits.value))
+    return mn.value, bits.value, out[: olen.value].copy()
+
+
+def int_decode(data, mn, bits, n, literal=True):
+    """intGroup.readData"""
+    data = _c(data, np.uint8)
+    padded = np.concatenate([data, np.zeros(16, np.uint8)])
+    out = np.empty(n, dtype=np.int64)
+    scratch = np.empty(max(n, 1), dtype=np.uint64)
+    rc = lib().mnwo_int_decode(_ptr(padded), int(mn), int(bits), int(n), _ptr(out),
+                               _ptr(scratch), int(literal))
+    if rc:
+        raise ValueError("oracle int_decode failed rc=%d" % rc)
+    return out
+
+
+def quantize(x, low, high, pixels):
+    """floatGroup.writeData's quantize loop (group.go:316-320)"""
+    x = _c(x, np.float32)
+    q = np.empty(x.size, dtype=np.int64)
+    lib().mnwo_quantize(_ptr(x), x.size, float(np.float32(low)), float(np.float32(high)),
+                        int(pixels), _ptr(q))
+    return q
+
+
+def float_encode(x, low, high, pixels, periodic=True, literal=True):
+    """floatGroup.writeData -> (min, bits, stream bytes)"""
+    x = _c(x, np.float32)
+    n = x.size
+    out = np.zeros(8 * n + 8, dtype=np.uint8)
+    qbuf = np.empty(max(n, 1), dtype=np.int64)
+    scratch = np.empty(max(n, 1), dtype=np.uint64)
+    mn, bits, olen = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = lib().mnwo_float_encode(_ptr(x), n, float(np.float32(low)), float(np.float32(high)),
+                                 int(pixels), int(bool(periodic)), C.byref(mn), C.byref(bits),
+                                 _ptr(out), C.byref(olen), _ptr(qbuf), _ptr(scratch),
+                                 int(literal))
+    if rc:
+        raise ValueError("oracle float_encode failed rc=%d (bits=%d)" % (rc, bits.value))
+    return mn.value, bits.value, out[: olen.value].copy()
+
+
+def float_decode_q(data, mn, bits, pixels, periodic, n, literal=True):
+    """integer stream of floatGroup.readData before dequantize (group.go:301-303)"""
+    data = _c(data, np.uint8)
+    padded = np.concatenate([data, np.zeros(16, np.uint8)])
+    q = np.empty(n, dtype=np.int64)
+    scratch = np.empty(max(n, 1), dtype=np.uint64)
+    rc = lib().mnwo_float_decode_q(_ptr(padded), int(mn), int(bits), int(pixels),
+                                   int(bool(periodic)), int(n), _ptr(q), _ptr(scratch),
+                                   int(literal))
+    if rc:
+        raise ValueError("oracle float_decode_q failed rc=%d" % rc)
+    return q
+
+
+def dither(seed, block, n):
+    u = np.empty(n, dtype=np.float64)
+    lib().mnwo_dither_fill(C.c_uint64(seed), C.c_uint64(block), int(n), _ptr(u))
+    return u
+
+
+def float_decode(data, mn, bits, low, high, pixels, periodic, n, u=None, literal=True):
+    """floatGroup.readData with explicit dither deviates u (None -> 0.0)"""
+    data = _c(data, np.uint8)
+    padded = np.concatenate([data, np.zeros(16, np.uint8)])
+    out = np.empty(n, dtype=np.float32)
+    qbuf = np.empty(max(n, 1), dtype=np.int64)
+    scratch = np.empty(max(n, 1), dtype=np.uint64)
+    up = None
+    if u is not None:
+        u = _c(u, np.float64)
+        up = _ptr(u)
+    rc = lib().mnwo_float_decode(_ptr(padded), int(mn), int(bits), float(np.float32(low)),
+                                 float(np.float32(high)), int(pixels), int(bool(periodic)),
+                                 up, int(n), _ptr(out), _ptr(qbuf), _ptr(scratch), int(literal))
+    if rc:
+        raise ValueError("oracle float_decode failed rc=%d" % rc)
+    return out
+
+
+def tail_array_encode(x):
+    """write(x) inside intGroup.writeTail (group.go:216-225)"""
+    x = _c(x, np.int64)
+    out = np.zeros(16 + 8 * x.size + 8, dtype=np.uint8)
+    n = lib().mnwo_tail_array_encode(_ptr(x), x.size, _ptr(out))
+    if n < 0:
+        raise ValueError("oracle tail encode failed")
+    return out[:n].copy()
+
+
+def tail_array_decode(data, blocks):
+    """read() inside newIntGroupFromTail (group.go:190-198) -> (values, bytes consumed)"""
+    data = _c(data, np.uint8)
+    padded = np.concatenate([data, np.zeros(16, np.uint8)])
+    out = np.empty(blocks, dtype=np.int64)
+    n = lib().mnwo_tail_array_decode(_ptr(padded), int(blocks), _ptr(out))
+    if n < 0:
+        raise ValueError("oracle tail decode failed")
+    return out, int(n)

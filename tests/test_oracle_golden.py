@@ -1,0 +1,201 @@
+"""Pins the CPU oracle (oracle/mnw_oracle.c) against the reference's own outputs.
+
+Fixtures under tests/golden/ were produced by tests/golden/make_golden.py from the reference's
+Python/Cython codec (python/cy_bit.pyx, python/minnow.py) and from the literal vectors of the
+reference's Go tests (go/bit/bit_test.go, go/minnow_test.go, python/minnow_test.py).
+"""
+import numpy as np
+import pytest
+
+
+def test_pack_3bit_known_answer(oracle, golden):
+    small, _ = golden
+    assert small["pack_3bit_12345"] == "d158"
+    assert oracle.pack(3, [1, 2, 3, 4, 5]).tobytes().hex() == "d158"
+    assert oracle.pack(3, [1, 2, 3, 4, 5], literal=False).tobytes().hex() == "d158"
+
+
+def test_pack_unpack_kat_all_widths(oracle, golden):
+    """bit.array/from_array outputs, widths 1..64 x ragged lengths (cf. bit_test.go:9-31)."""
+    _, kat = golden
+    X, idx, blob = kat["pack_X"], kat["pack_index"], kat["pack_blob"]
+    for b, L, pos, nbytes in idx:
+        b, L, pos, nbytes = int(b), int(L), int(pos), int(nbytes)
+        mask = np.uint64((1 << b) - 1)
+        x = X[:L] & mask
+        want = blob[pos:pos + nbytes]
+        assert oracle.array_bytes(b, L) == nbytes
+        for literal in (True, False):
+            # un-masked input: Go masks inside BufferedArray (bit.go:104-107)
+            got = oracle.pack(b, X[:L], literal=literal)
+            assert np.array_equal(got, want), (b, L, literal)
+            back = oracle.unpack(b, want, L, literal=literal)
+            assert np.array_equal(back, x), (b, L, literal)
+
+
+def test_go_testarray_shape(oracle):
+    """go/bit/bit_test.go:9-31: 123 random 63-bit values, every width, out == data & mask."""
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 2**63, size=123, dtype=np.uint64)
+    for bits in range(1, 65):
+        mask = np.uint64((1 << bits) - 1)
+        for literal in (True, False):
+            arr = oracle.pack(bits, data, literal=literal)
+            out = oracle.unpack(bits, arr, data.size, literal=literal)
+            assert np.array_equal(out, data & mask)
+
+
+def test_go_testarraybuffer_shape(oracle):
+    """go/bit/bit_test.go:33-69: lengths 10,5,1,20, values j, widths from Bits()."""
+    for n in (10, 5, 1, 20):
+        data = np.arange(n, dtype=np.uint64)
+        bits = oracle.bits_needed(data)
+        assert bits == int(n - 1).bit_length()
+        if bits == 0:
+            continue
+        arr = oracle.pack(bits, data)
+        assert np.array_equal(oracle.unpack(bits, arr, n), data)
+
+
+def test_pack_errors(oracle):
+    from oracle import oracle as o
+    import ctypes as C
+    x = np.zeros(4, np.uint64)
+    out = np.zeros(64, np.uint8)
+    assert o.lib().mnwo_pack(65, o._ptr(x), 4, o._ptr(out), 33) == -1   # bit.go:85-87
+    assert o.lib().mnwo_pack(8, o._ptr(x), 4, o._ptr(out), 5) == -2     # bit.go:88-92
+
+
+def test_precision_needed(oracle, golden):
+    small, _ = golden
+    for m, want in small["precision_needed_lt_2p48"]:
+        assert oracle.precision_needed(m) == want == int(m).bit_length(), m
+    # Go's Log2 special-cases exact powers of two (frac == 0.5)
+    for k in range(0, 64):
+        assert oracle.precision_needed(2**k - 1) == k
+    # at max = 2^49 the float formula returns 49, not 50 (parity unpinned above 2^49)
+    assert oracle.precision_needed(2**49) == 49
+    assert oracle.precision_needed(2**48) == 49
+    # max = 2^64-1: max+1 wraps to 0, log2(0) = -Inf, int(-Inf) = MinInt64 on amd64
+    assert oracle.precision_needed(2**64 - 1) == -(2**63)
+
+
+def test_array_bytes(oracle, golden):
+    small, _ = golden
+    for b, L, want in small["array_bytes"]:
+        assert oracle.array_bytes(b, L) == want == (b * L + 7) // 8
+
+
+def test_periodic_min_reference_table(oracle, golden):
+    small, _ = golden
+    t = small["periodic_min_table"]
+    for d, m in zip(t["data"], t["mins"]):
+        assert oracle.periodic_min(d, t["pixels"]) == m
+
+
+def test_periodic_min_random(oracle, golden):
+    small, _ = golden
+    for pixels, x, want in small["periodic_min_random"]:
+        assert oracle.periodic_min(x, pixels) == want, (pixels, x)
+    assert oracle.periodic_min([], 20) == 0          # group.go:385
+
+
+def test_int_group_golden(oracle, golden):
+    small, _ = golden
+    for case in small["int_group"]:
+        x = np.array(case["x"], dtype=np.int64)
+        want = bytes.fromhex(case["bytes"])
+        for literal in (True, False):
+            mn, bits, data = oracle.int_encode(x, literal=literal)
+            assert (mn, bits) == (case["min"], case["bits"]), case["x"][:4]
+            assert data.tobytes() == want
+            back = oracle.int_decode(data, mn, bits, x.size, literal=literal)
+            assert np.array_equal(back, x)
+
+
+def test_int_group_edge_cases(oracle):
+    mn, bits, data = oracle.int_encode(np.zeros(0, np.int64))
+    assert (mn, bits, data.size) == (0, 0, 0)         # group.go:351, bit.go:152
+    mn, bits, data = oracle.int_encode([1024, 1024, 1024])
+    assert (mn, bits, data.size) == (1024, 0, 0)      # constant block costs 0 bytes
+    x = np.array([-(2**63), 2**63 - 2], dtype=np.int64)   # range 2^64-2 -> 64 bits
+    mn, bits, data = oracle.int_encode(x)
+    assert bits == 64 and data.size == 16
+    assert np.array_equal(oracle.int_decode(data, mn, bits, 2), x)
+
+
+def test_float_group_golden(oracle, golden):
+    small, _ = golden
+    for case in small["float_group"]:
+        x = np.frombuffer(bytes.fromhex(case["x_f32_hex"]), dtype="<f4")
+        assert oracle.float_group_pixels(case["low"], case["high"], case["dx"]) == case["pixels"]
+        for literal in (True, False):
+            mn, bits, data = oracle.float_encode(x, case["low"], case["high"], case["pixels"],
+                                                 literal=literal)
+            assert (mn, bits) == (case["min"], case["bits"])
+            assert data.tobytes() == bytes.fromhex(case["bytes"])
+
+
+def test_float_group_pixels_go_vs_python(oracle):
+    """(10, 14, 0.01) -> Go float32 derivation gives 400, Python float64 gives 401."""
+    assert oracle.float_group_pixels(10, 14, 0.01) == 400
+    assert oracle.float_group_pixels(0, 250, 0.001) == 250000
+    assert oracle.float_group_pixels(-50, 100, 1) == 150
+    assert oracle.float_group_pixels(-50, 100, 10) == 15
+
+
+def test_float_roundtrip_go_test_vectors(oracle):
+    """go/minnow_test.go:270-310 TestQFloatRecord: |x - x'| <= dx (float32sEq)."""
+    low, high = -50.0, 100.0
+    for dx, blocks in ((1.0, [[-50, 0, 50, 49], [25, 25, 25, 25]]),
+                       (10.0, [[-50, 0, 50, 49, 0], [1, 2, 3, 4, 5], [0, 20, 0, 20, 0]])):
+        pixels = oracle.float_group_pixels(low, high, dx)
+        for bi, blk in enumerate(blocks):
+            x = np.array(blk, dtype=np.float32)
+            mn, bits, data = oracle.float_encode(x, low, high, pixels)
+            if blk == [25, 25, 25, 25]:
+                assert bits == 0 and data.size == 0
+            u = oracle.dither(7, bi, x.size)
+            assert ((u >= 0) & (u < 1)).all()
+            y = oracle.float_decode(data, mn, bits, low, high, pixels, True, x.size, u=u)
+            assert np.all(np.abs(y - x) <= np.float32(dx))
+
+
+def test_tail_arrays_golden(oracle, golden):
+    small, _ = golden
+    for case in small["tail_arrays"]:
+        raw = bytes.fromhex(case["tail_hex"])
+        x = np.array(case["x"], dtype=np.int64)
+        enc = oracle.tail_array_encode(x)
+        assert raw[24:24 + enc.size] == enc.tobytes()
+        back, used = oracle.tail_array_decode(np.frombuffer(raw[24:], np.uint8), x.size)
+        assert np.array_equal(back, x) and used == enc.size
+
+
+def test_periodic_reduction_identity(oracle):
+    """for q in [0, pixels) periodicMin equals a function of four reductions
+    (min/max of the values below and at-or-above pixels/2).  Checked against the sequential
+    restatement of group.go:384-409."""
+    rng = np.random.default_rng(5)
+
+    def by_reduction(q, pixels):
+        h = pixels // 2
+        lo, hi = q[q < h], q[q >= h]
+        mn0, mx0 = q.min(), q.max()
+        if mx0 - mn0 + 1 <= h:
+            return int(mn0)
+        if lo.size and hi.size:
+            mn1, mx1 = hi.min(), lo.max() + pixels
+        elif hi.size:
+            mn1, mx1 = hi.min(), hi.max()
+        else:
+            mn1, mx1 = lo.min() + pixels, lo.max() + pixels
+        if mx1 - mn1 + 1 <= h:
+            return int(mn1 % pixels) if mn1 >= pixels else int(mn1)
+        return 0
+
+    for _ in range(20000):
+        pixels = int(rng.integers(1, 70))
+        n = int(rng.integers(1, 14))
+        q = rng.integers(0, pixels, size=n).astype(np.int64)
+        assert by_reduction(q, pixels) == oracle.periodic_min(q, pixels), (pixels, q)
