@@ -1,0 +1,183 @@
+/*
+ * minnow_hip.h -- C ABI of libminnow_hip.so: minnow's column quantize + bit-pack hot path
+ * on MI355X (gfx950), hand-written HIP kernels behind plain pointers and sizes.
+ *
+ * This is the drop-in boundary for the reference's Go code: a cgo shim replaces the BODIES of
+ *   intGroup.writeData / readData      go/group.go:242-255, 257-263
+ *   floatGroup.writeData / readData    go/group.go:312-327, 299-310
+ *   bit.BufferedArray / (*Array).Slice go/bit/bit.go:84-134, 29-82
+ * up to (not including) f.Write / f.Read; file I/O, the per-group mins/bits slices and
+ * blockIndex.addBlock stay in Go.  INTEGRATION.md shows the binding.  Every entry point names the
+ * reference function it replaces.  All sizes are in elements unless they end in _len/_bytes/cap.
+ *
+ * Error convention: the reference panics on every error (go/writer.go:34,91-95; bit.go:31,86,90);
+ * a C ABI cannot, so every call returns an int status (0 = MNW_OK) and the shim re-panics.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ * MNW_E_NOGPU.
+ */
+#ifndef MINNOW_HIP_H
+#define MINNOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNW_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define MNW_OK            0
+#define MNW_E_ARG        (-1)  /* null pointer, negative length, bits > 64 (bit.go:85-87) */
+#define MNW_E_BUFLEN     (-2)  /* buffer length != ArrayBytes(bits, n) (bit.go:88-92) / out too short (bit.go:30-33) */
+#define MNW_E_NOGPU      (-3)  /* no HIP device: the product path has no CPU fallback */
+#define MNW_E_HIP        (-4)  /* HIP runtime error; see mnw_last_error() */
+#define MNW_E_CAPACITY   (-5)  /* packed stream does not fit the caller's out capacity */
+#define MNW_E_DOMAIN     (-6)  /* width outside 0..64: max-min == 2^64-1 makes Go's PrecisionNeeded
+                                  return int(-Inf) (bit.go:19-21) and the reference panic later */
+#define MNW_E_NOMEM      (-7)
+
+/* group-type constants of the reference (go/group.go:11-24); only these two are codec paths */
+#define MNW_INT_GROUP    10
+#define MNW_FLOAT_GROUP  11
+
+typedef struct mnw_ctx mnw_ctx;       /* one per Writer/Reader; not thread-safe, like the reference */
+typedef void *mnw_stream_t;           /* a hipStream_t (NULL = the context's own stream) */
+
+/* ---- context --------------------------------------------------------------------------- */
+int mnw_ctx_create(int device, mnw_ctx **ctx);
+int mnw_ctx_destroy(mnw_ctx *ctx);
+const char *mnw_strerror(int status);
+const char *mnw_last_error(const mnw_ctx *ctx);
+int mnw_abi_version(void);
+/* number of HIP devices visible (0 when none / no driver); never initialises a context */
+int mnw_device_count(void);
+
+/* ---- scalars (host arithmetic, no GPU needed) -------------------------------------------- */
+/* bit.PrecisionNeeded, go/bit/bit.go:19-21: int(ceil(log2(float64(max+1)))) with Go's math.Log2 */
+int64_t mnw_precision_needed(uint64_t max);
+/* bit.ArrayBytes, go/bit/bit.go:23-25 */
+int64_t mnw_array_bytes(int64_t bits, int64_t length);
+/* pixels of Writer.FloatGroup, go/writer.go:72-75 (float32 subtract and divide, float64 ceil) */
+int64_t mnw_float_group_pixels(float low, float high, float dx);
+
+/* ---- host-pointer, synchronous forms: what the cgo shim binds ---------------------------------
+ * Inputs/outputs are ordinary host memory (Go slices); the call stages them through the context's
+ * pinned buffers, runs the kernels and returns when the result is in the caller's memory.  No
+ * pointer is retained after return (cgo rule). */
+
+/* bit.BufferedArray(bits, x, b), bit.go:84-134: packs x[i] & mask at `bits` bits, LSB first.
+ * out_len must equal ArrayBytes(bits, n). */
+int mnw_pack_u64(mnw_ctx *ctx, const uint64_t *x, int64_t n, int bits, uint8_t *out, int64_t out_len);
+/* (*bit.Array).Slice(out), bit.go:29-82.  in_len must be >= ArrayBytes(bits, n). */
+int mnw_unpack_u64(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int bits, int64_t n, uint64_t *out);
+
+/* intGroup.writeData, group.go:242-250: min, buf = x-min, bits = Bits(buf), pack.
+ * *out_len = ArrayBytes(bits, n), 0 when bits == 0 (bit.go:162).  cap = capacity of out. */
+int mnw_int_encode(mnw_ctx *ctx, const int64_t *x, int64_t n, int64_t *min, int64_t *bits,
+                   uint8_t *out, int64_t cap, int64_t *out_len);
+/* intGroup.readData, group.go:257-263 (bits == 0 -> all min, bit.go:171-174) */
+int mnw_int_decode(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int64_t min, int64_t bits,
+                   int64_t n, int64_t *out);
+
+/* floatGroup.writeData, group.go:312-327: quantize, periodicMin + bound when periodic == 1,
+ * then the intGroup path. */
+int mnw_float_encode(mnw_ctx *ctx, const float *x, int64_t n, float low, float high, int64_t pixels,
+                     int periodic, int64_t *min, int64_t *bits, uint8_t *out, int64_t cap,
+                     int64_t *out_len);
+/* floatGroup.readData, group.go:299-310.  The reference dithers with the global math/rand stream
+ * (group.go:308), which no other program can reproduce; here the uniform deviate of element i is a
+ * counter-based function of (seed, block, i) (DESIGN.md "Dither"), so decodes are reproducible. */
+int mnw_float_decode(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int64_t min, int64_t bits,
+                     float low, float high, int64_t pixels, int periodic, uint64_t seed,
+                     uint64_t block, int64_t n, float *out);
+
+/* ---- device-pointer, batched forms: per-column blocks as the unit of GPU dispatch --------------
+ * src/dst are DEVICE pointers (hipMalloc / torch tensors).  One call enqueues every block of the
+ * batch on `stream`; blocks are independent (group.go:242-255 depends on one block only).  The
+ * packed stream of block k is written at dst (8-byte aligned, capacity cap bytes); its exact
+ * length comes back in meta[k].nbytes, which is what blockIndex.addBlock receives
+ * (block_index.go:16-23). */
+typedef struct mnw_enc_job {
+    const void *src;     /* device: float32[n] (MNW_FLOAT_GROUP) or int64[n] (MNW_INT_GROUP) */
+    void *dst;           /* device: packed stream, 8-byte aligned */
+    int64_t n;           /* elements in the block */
+    int64_t cap;         /* bytes available at dst */
+    int64_t pixels;      /* float groups: floatGroup.pixels */
+    float low, high;     /* float groups: floatGroup.low / high */
+    int32_t kind;        /* MNW_INT_GROUP or MNW_FLOAT_GROUP */
+    int32_t periodic;    /* float groups: floatGroup.periodic (1 from Writer.FloatGroup, writer.go:74) */
+} mnw_enc_job;
+
+typedef struct mnw_dec_job {
+    const void *src;     /* device: packed stream, ANY byte alignment (file offsets are byte-granular) */
+    void *dst;           /* device: float32[n] or int64[n] */
+    int64_t n;
+    int64_t src_len;     /* bytes available at src; must be >= ArrayBytes(bits, n) */
+    int64_t min;         /* intGroup.mins[b] */
+    int64_t bits;        /* intGroup.bits[b] */
+    int64_t pixels;
+    float low, high;
+    int32_t kind;
+    int32_t periodic;
+    uint64_t seed;       /* dither key (float groups) */
+    uint64_t block;      /* dither key: block index */
+} mnw_dec_job;
+
+typedef struct mnw_block_meta {
+    int64_t min;         /* what intGroup.writeData appends to g.mins (group.go:251) */
+    int64_t bits;        /* ... and to g.bits (group.go:252) */
+    int64_t nbytes;      /* bytes written at dst = ArrayBytes(bits, n), 0 when bits == 0 */
+    int64_t status;      /* MNW_OK, MNW_E_CAPACITY or MNW_E_DOMAIN for this block */
+} mnw_block_meta;
+
+/* Encode njobs blocks.  jobs and meta are HOST arrays.  Synchronous with respect to meta: returns
+ * after the kernels have finished and meta[] is filled (the widths are data dependent, and the
+ * caller needs them for its block index).  Returns the first non-OK block status, else MNW_OK. */
+int mnw_encode_blocks(mnw_ctx *ctx, mnw_stream_t stream, const mnw_enc_job *jobs, int njobs,
+                      mnw_block_meta *meta);
+/* Split form for pipelining: enqueue only (no host synchronisation) ... */
+int mnw_encode_blocks_async(mnw_ctx *ctx, mnw_stream_t stream, const mnw_enc_job *jobs, int njobs);
+/* ... then collect the metadata of the most recent async batch (synchronises the stream). */
+int mnw_encode_blocks_finish(mnw_ctx *ctx, mnw_stream_t stream, mnw_block_meta *meta);
+
+/* Decode njobs blocks; enqueue only (widths are known from the group tail, group.go:186-213).
+ * The caller synchronises `stream`. */
+int mnw_decode_blocks(mnw_ctx *ctx, mnw_stream_t stream, const mnw_dec_job *jobs, int njobs);
+
+/* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
+ * dst of pack must hold ArrayBytes(bits, n) rounded up to 8 bytes. */
+int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
+                     uint8_t *out, int64_t cap);
+int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int64_t in_len, int bits,
+                       int64_t n, uint64_t *out);
+
+/* ---- instrumentation ------------------------------------------------------------------- */
+/* Per-kernel device time of the launches made through this context since the last reset, measured
+ * with HIP events on the stream each kernel was launched on (bench.py's roofline leg).  Enabling
+ * timing inserts event records around every launch. */
+#define MNW_K_REDUCE_F32  0
+#define MNW_K_PACK_F32    1
+#define MNW_K_REDUCE_I64  2
+#define MNW_K_PACK_I64    3
+#define MNW_K_UNPACK_F32  4
+#define MNW_K_UNPACK_I64  5
+#define MNW_K_COUNT       8
+typedef struct mnw_kernel_time {
+    double total_ms;     /* sum of event-timed durations */
+    int64_t launches;
+} mnw_kernel_time;
+int mnw_timing_enable(mnw_ctx *ctx, int on);
+int mnw_timing_reset(mnw_ctx *ctx);
+int mnw_timing_get(mnw_ctx *ctx, mnw_kernel_time *out /* [MNW_K_COUNT] */);
+const char *mnw_kernel_name(int kernel_id);
+
+/* Tunables (0 = default).  group_bytes: blocks are launched in groups whose input is at most this
+ * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM. */
+int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINNOW_HIP_H */

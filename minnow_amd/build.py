@@ -1,0 +1,44 @@
+"""Builds libminnow_hip.so (the C-ABI library) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so then travels to
+the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libminnow_hip.so")
+SOURCES = ["mnw_kernels.hip", "mnw_api.cpp"]
+HEADERS = ["mnw_common.h", os.path.join("..", "..", "include", "minnow_hip.h")]
+
+# -ffp-contract=off: the reference's float32 expressions are never fused (Go on amd64);
+# correctly rounded f32 divide and denormal support are hipcc defaults, stated explicitly here.
+FLAGS = [
+    "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
+    "-fno-fast-math", "-x", "hip", "-Wall", "-Wno-unused-function",
+]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,155 @@
+"""Context + batched block jobs over the C ABI (device pointers in, device pointers out).
+
+torch is used only as plumbing by callers (device memory, streams); this module takes raw device
+pointers (``tensor.data_ptr()``) and stream handles (``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+from . import _lib
+from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MnwError
+
+INT_GROUP = 10     # go/group.go:22
+FLOAT_GROUP = 11   # go/group.go:23
+
+
+@dataclass
+class EncJob:
+    """One block to encode: what Writer.Data hands to group.writeData (writer.go:90-103)."""
+    src: int               # device pointer: float32[n] or int64[n]
+    dst: int               # device pointer, 8-byte aligned
+    n: int
+    cap: int
+    kind: int = FLOAT_GROUP
+    low: float = 0.0
+    high: float = 0.0
+    pixels: int = 0
+    periodic: int = 1      # Writer.FloatGroup hard-codes periodic = true (writer.go:74)
+
+
+@dataclass
+class DecJob:
+    """One block to decode: what Reader.Data hands to group.readData (reader.go:114-127)."""
+    src: int               # device pointer to the packed stream (any byte alignment)
+    dst: int               # device pointer: float32[n] or int64[n]
+    n: int
+    src_len: int
+    min: int
+    bits: int
+    kind: int = FLOAT_GROUP
+    low: float = 0.0
+    high: float = 0.0
+    pixels: int = 0
+    periodic: int = 1
+    seed: int = 0
+    block: int = 0
+
+
+@dataclass
+class BlockMeta:
+    min: int       # appended to intGroup.mins (group.go:251)
+    bits: int      # appended to intGroup.bits (group.go:252)
+    nbytes: int    # argument of blockIndex.addBlock (group.go:254); 0 when bits == 0
+    status: int
+
+
+class Context:
+    """One per Writer/Reader; not thread-safe, like the reference's Writer (writer.go:10-22)."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.mnw_ctx_create(int(device), C.byref(h))
+        if rc:
+            raise MnwError(rc, self._L.mnw_strerror(rc).decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mnw_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc:
+            raise MnwError(rc, self._L.mnw_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_option(self, name, value):
+        self._check(self._L.mnw_set_option(self._h, name.encode(), int(value)))
+
+    # -- batched device-pointer API -----------------------------------------------------------
+    @staticmethod
+    def _enc_array(jobs):
+        arr = (EncJobC * max(len(jobs), 1))()
+        for i, j in enumerate(jobs):
+            arr[i] = EncJobC(j.src, j.dst, j.n, j.cap, j.pixels, j.low, j.high, j.kind, j.periodic)
+        return arr
+
+    def encode_blocks(self, jobs, stream=None, check=True):
+        arr = self._enc_array(jobs)
+        meta = (BlockMetaC * max(len(jobs), 1))()
+        rc = self._L.mnw_encode_blocks(self._h, stream, arr, len(jobs), meta)
+        out = [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[: len(jobs)]]
+        if check:
+            self._check(rc)
+        return out
+
+    def encode_blocks_async(self, jobs, stream=None):
+        arr = self._enc_array(jobs)
+        self._check(self._L.mnw_encode_blocks_async(self._h, stream, arr, len(jobs)))
+        self._pending_n = len(jobs)
+
+    def encode_blocks_finish(self, stream=None, check=True):
+        n = self._pending_n
+        meta = (BlockMetaC * max(n, 1))()
+        rc = self._L.mnw_encode_blocks_finish(self._h, stream, meta)
+        if check:
+            self._check(rc)
+        return [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[:n]]
+
+    def decode_blocks(self, jobs, stream=None):
+        arr = (DecJobC * max(len(jobs), 1))()
+        for i, j in enumerate(jobs):
+            arr[i] = DecJobC(j.src, j.dst, j.n, j.src_len, j.min, j.bits, j.pixels, j.low, j.high,
+                             j.kind, j.periodic, j.seed, j.block)
+        self._check(self._L.mnw_decode_blocks(self._h, stream, arr, len(jobs)))
+
+    def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
+        self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))
+
+    def unpack_u64_dev(self, in_ptr, in_len, bits, n, out_ptr, stream=None):
+        self._check(self._L.mnw_unpack_u64_dev(self._h, stream, in_ptr, in_len, bits, n, out_ptr))
+
+    # -- timing ------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._L.mnw_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._check(self._L.mnw_timing_reset(self._h))
+
+    def timing_get(self):
+        arr = (KernelTimeC * _lib.K_COUNT)()
+        self._check(self._L.mnw_timing_get(self._h, arr))
+        out = {}
+        for k in range(_lib.K_COUNT):
+            name = self._L.mnw_kernel_name(k).decode()
+            if name:
+                out[name] = {"total_ms": arr[k].total_ms, "launches": arr[k].launches}
+        return out

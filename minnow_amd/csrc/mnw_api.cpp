@@ -1,0 +1,732 @@
+// mnw_api.cpp -- C ABI of libminnow_hip.so (include/minnow_hip.h): contexts, staging, launch
+// scheduling and the exact path for order-dependent blocks.  Host side of the product; compiled by
+// hipcc together with mnw_kernels.hip.  No CPU fallback: every compute entry point needs a HIP device.
+#include "../../include/minnow_hip.h"
+#include "mnw_common.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace mnw {
+void launch_reduce_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
+void launch_reduce_i64(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
+void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
+void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
+void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
+void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
+void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
+void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
+void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
+}  // namespace mnw
+
+using mnw::DevJob;
+using mnw::Meta;
+
+static_assert(sizeof(Meta) == sizeof(mnw_block_meta), "meta layout");
+
+struct TimedLaunch {
+    int kernel;
+    hipEvent_t start, stop;
+};
+
+constexpr int kSlots = 3;
+struct JobSlot {
+    int cap = 0;
+    DevJob* d_jobs = nullptr;
+    DevJob* h_jobs = nullptr;     // pinned
+    uint64_t* d_stats = nullptr;
+    Meta* d_meta = nullptr;
+    Meta* h_meta = nullptr;       // pinned
+    hipEvent_t consumed = nullptr;
+    bool in_flight = false;
+};
+
+struct mnw_ctx {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // job / stats / meta arrays (grow-only, like bit.ArrayBuffer, bit.go:183-205).  A ring of
+    // slots so that a batch can be prepared while the kernels of earlier batches still read theirs;
+    // a slot is reused only after the event recorded behind its last consumer has completed.
+    JobSlot slots[kSlots];
+    int cur = 0;
+    JobSlot* pend = nullptr;      // slot of the pending async encode batch
+
+    // staging for the host-pointer entry points
+    size_t cap_in = 0, cap_out = 0;
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+
+    // exact path scratch
+    size_t cap_q = 0;
+    int64_t* d_q = nullptr;
+    int64_t* d_state = nullptr;
+
+    // pending async encode batch
+    bool pending = false;
+    std::vector<mnw_enc_job> pend_jobs;
+    std::vector<int> pend_slot;    // caller index -> device job slot (-1: handled on the host)
+    std::vector<Meta> pend_host;   // host-resolved metas
+    hipStream_t pend_stream = nullptr;
+
+    // options
+    int64_t group_bytes = 96ll << 20;
+    int grid_cap = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> event_pool;
+    mnw_kernel_time acc[MNW_K_COUNT];
+};
+
+namespace {
+
+int fail(mnw_ctx* c, int status, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        c->err = buf;
+    }
+    return status;
+}
+
+#define HIPCHK(c, call)                                                          \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return fail((c), MNW_E_HIP, #call, e_);            \
+    } while (0)
+
+void free_slot(JobSlot& sl) {
+    if (sl.d_jobs) { hipFree(sl.d_jobs); hipFree(sl.d_stats); hipFree(sl.d_meta); hipHostFree(sl.h_jobs); hipHostFree(sl.h_meta); }
+    sl.d_jobs = nullptr; sl.cap = 0;
+}
+
+// next ring slot with room for n jobs; waits (host side) only if that slot's previous batch is
+// still being consumed by the GPU
+int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
+    c->cur = (c->cur + 1) % kSlots;
+    JobSlot& sl = c->slots[c->cur];
+    if (&sl == c->pend) { c->cur = (c->cur + 1) % kSlots; return acquire_slot(c, n, out); }
+    if (!sl.consumed) HIPCHK(c, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+    if (sl.in_flight) { HIPCHK(c, hipEventSynchronize(sl.consumed)); sl.in_flight = false; }
+    if (n > sl.cap) {
+        int cap = sl.cap ? sl.cap : 64;
+        while (cap < n) cap *= 2;
+        free_slot(sl);
+        HIPCHK(c, hipMalloc((void**)&sl.d_jobs, sizeof(DevJob) * cap));
+        HIPCHK(c, hipMalloc((void**)&sl.d_stats, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * cap));
+        HIPCHK(c, hipMalloc((void**)&sl.d_meta, sizeof(Meta) * cap));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_jobs, sizeof(DevJob) * cap, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocDefault));
+        sl.cap = cap;
+    }
+    *out = &sl;
+    return MNW_OK;
+}
+
+int release_slot(mnw_ctx* c, JobSlot* sl, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(sl->consumed, s));
+    sl->in_flight = true;
+    return MNW_OK;
+}
+
+int ensure_dev(mnw_ctx* c, void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return MNW_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t want = need + need / 4 + 256;
+    HIPCHK(c, hipMalloc(p, want));
+    *cap = want;
+    return MNW_OK;
+}
+
+hipEvent_t get_event(mnw_ctx* c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {   // event pair around one kernel launch, on the launch's own stream
+    mnw_ctx* c; hipStream_t s; TimedLaunch t; bool on;
+    ScopedTimer(mnw_ctx* c_, hipStream_t s_, int kernel) : c(c_), s(s_), on(c_->timing) {
+        if (on) { t.kernel = kernel; t.start = get_event(c); t.stop = get_event(c); hipEventRecord(t.start, s); }
+    }
+    ~ScopedTimer() { if (on) { hipEventRecord(t.stop, s); c->launches.push_back(t); } }
+};
+
+int grid_for(mnw_ctx* c, int64_t tiles) {
+    int cap = c->grid_cap > 0 ? c->grid_cap : c->cus * 8;
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
+// smallest float32 >= pixels/2 (the float split point of the reduce pass)
+float ceil_f32_of(int64_t h) {
+    float f = (float)h;                  // round to nearest
+    if ((double)f < (double)h) f = nextafterf(f, INFINITY);
+    return f;
+}
+
+// (high-low)/float32(pixels) in IEEE float32, group.go:316
+float quant_dx(float low, float high, int64_t pixels) {
+    volatile float span = high - low;
+    volatile float p = (float)pixels;
+    volatile float dx = span / p;
+    return dx;
+}
+
+bool job_ok(const mnw_enc_job& j) {
+    if (j.n < 0 || j.cap < 0) return false;
+    if (j.kind != MNW_INT_GROUP && j.kind != MNW_FLOAT_GROUP) return false;
+    if (j.n > 0 && (!j.src || (!j.dst && j.cap > 0))) return false;
+    if (((uintptr_t)j.dst & 7) != 0) return false;
+    if (j.n > (1ll << 47)) return false;
+    return true;
+}
+
+void fill_enc(DevJob& d, const mnw_enc_job& j) {
+    memset(&d, 0, sizeof d);
+    d.src = j.src; d.dst = j.dst; d.n = j.n; d.cap = j.cap; d.pixels = j.pixels;
+    d.low = j.low; d.high = j.high; d.kind = j.kind; d.periodic = j.periodic;
+    d.mode = mnw::kModeStats;
+    if (j.kind == MNW_FLOAT_GROUP) {
+        d.dxq = quant_dx(j.low, j.high, j.pixels);
+        d.hf = ceil_f32_of(j.pixels / 2);
+    }
+}
+
+// Launch reduce+pack for device jobs [j0, j1) of one kind, in groups of at most group_bytes of input
+// so that the pack pass re-reads its group from the Infinity Cache.  tile0 is group relative.
+int launch_encode_range(mnw_ctx* c, JobSlot* sl, hipStream_t s, int j0, int j1, int kind) {
+    const int64_t esz = kind == MNW_FLOAT_GROUP ? 4 : 8;
+    int g0 = j0;
+    while (g0 < j1) {
+        int g1 = g0;
+        int64_t bytes = 0, tiles = 0;
+        while (g1 < j1 && (g1 == g0 || bytes + sl->h_jobs[g1].n * esz <= c->group_bytes)) {
+            bytes += sl->h_jobs[g1].n * esz;
+            tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
+            ++g1;
+        }
+        if (tiles > 0) {
+            const int grid = grid_for(c, tiles);
+            uint64_t* st = sl->d_stats + (size_t)g0 * mnw::kStatSlots * mnw::kStatWords;
+            if (kind == MNW_FLOAT_GROUP) {
+                { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st); }
+                { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sl->d_meta + g0); }
+            } else {
+                { ScopedTimer t(c, s, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st); }
+                { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sl->d_meta + g0); }
+            }
+            HIPCHK(c, hipGetLastError());
+        }
+        g0 = g1;
+    }
+    return MNW_OK;
+}
+
+// Encode int64 blocks that already sit in device memory, synchronously (used by the exact path and
+// by the host-pointer entry points).  Uses device job slot 0.
+int encode_one_sync(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, int mode, int64_t emin, int ebits, Meta* out) {
+    JobSlot* sl;
+    int rc = acquire_slot(c, 1, &sl);
+    if (rc) return rc;
+    DevJob& d = sl->h_jobs[0];
+    fill_enc(d, job);
+    d.mode = mode; d.min = emin; d.bits = ebits; d.tile0 = 0;
+    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords, s));
+    const int64_t tiles = (job.n + mnw::kTile - 1) / mnw::kTile;
+    const int grid = grid_for(c, tiles);
+    if (job.kind == MNW_FLOAT_GROUP) {
+        { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats); }
+        { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
+    } else {
+        if (mode == mnw::kModeStats) { ScopedTimer t(c, s, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats); }
+        { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *out = sl->h_meta[0];
+    return MNW_OK;
+}
+
+// floatGroup.writeData for a block whose periodicMin depends on element order: the literal sequence
+// of group.go:312-327 on the GPU (quantize -> sequential periodicMin -> bound -> intGroup path).
+int encode_exact_float(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, Meta* out) {
+    int rc = ensure_dev(c, (void**)&c->d_q, &c->cap_q, (size_t)job.n * 8);
+    if (rc) return rc;
+    if (!c->d_state) HIPCHK(c, hipMalloc((void**)&c->d_state, 4 * sizeof(int64_t)));
+    const float dx = quant_dx(job.low, job.high, job.pixels);
+    const int grid = (int)((job.n + mnw::kThreads - 1) / mnw::kThreads < c->cus * 8 ? (job.n + mnw::kThreads - 1) / mnw::kThreads : c->cus * 8);
+    mnw::launch_quantize_i64(s, grid, (const float*)job.src, job.n, job.low, dx, c->d_q);
+    if (job.periodic == 1) {
+        int64_t st[4] = {0, 1, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(c->d_state, st, sizeof st, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const int64_t budget = 1ll << 22;
+        for (int64_t done = 0; done < job.n; done += budget)
+            mnw::launch_periodic_min_seq(s, c->d_q, job.n, job.pixels, budget, c->d_state);
+        HIPCHK(c, hipMemcpyAsync(st, c->d_state, sizeof st, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        const int64_t pmin = st[2] ? 0 : st[0];
+        mnw::launch_bound_i64(s, grid, c->d_q, job.n, pmin, job.pixels);
+    }
+    HIPCHK(c, hipGetLastError());
+    mnw_enc_job ij = job;
+    ij.kind = MNW_INT_GROUP;
+    ij.src = c->d_q;
+    return encode_one_sync(c, s, ij, mnw::kModeStats, 0, 0, out);
+}
+
+int status_of(const Meta& m) { return (int)m.status; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int mnw_abi_version(void) { return MNW_ABI_VERSION; }
+
+int mnw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mnw_strerror(int status) {
+    switch (status) {
+        case MNW_OK: return "ok";
+        case MNW_E_ARG: return "bad argument (null pointer, negative length, bits > 64, misaligned dst)";
+        case MNW_E_BUFLEN: return "buffer length does not match ArrayBytes(bits, n)";
+        case MNW_E_NOGPU: return "no HIP device available (libminnow_hip has no CPU fallback)";
+        case MNW_E_HIP: return "HIP runtime error";
+        case MNW_E_CAPACITY: return "packed stream does not fit the output capacity";
+        case MNW_E_DOMAIN: return "bit width outside 0..64 (max-min == 2^64-1)";
+        case MNW_E_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* mnw_last_error(const mnw_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char* mnw_kernel_name(int k) {
+    switch (k) {
+        case MNW_K_REDUCE_F32: return "k_reduce_f32";
+        case MNW_K_PACK_F32: return "k_pack_f32";
+        case MNW_K_REDUCE_I64: return "k_reduce_i64";
+        case MNW_K_PACK_I64: return "k_pack_i64";
+        case MNW_K_UNPACK_F32: return "k_unpack_f32";
+        case MNW_K_UNPACK_I64: return "k_unpack_i64";
+        default: return "";
+    }
+}
+
+int mnw_ctx_create(int device, mnw_ctx** out) {
+    if (!out) return MNW_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MNW_E_NOGPU;
+    if (device < 0 || device >= n) return MNW_E_ARG;
+    mnw_ctx* c = new (std::nothrow) mnw_ctx();
+    if (!c) return MNW_E_NOMEM;
+    c->device = device;
+    memset(c->acc, 0, sizeof c->acc);
+    if (hipSetDevice(device) != hipSuccess) { delete c; return MNW_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MNW_E_HIP; }
+    *out = c;
+    return MNW_OK;
+}
+
+int mnw_ctx_destroy(mnw_ctx* c) {
+    if (!c) return MNW_E_ARG;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& t : c->launches) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (auto& sl : c->slots) { free_slot(sl); if (sl.consumed) hipEventDestroy(sl.consumed); }
+    if (c->d_in) hipFree(c->d_in);
+    if (c->d_out) hipFree(c->d_out);
+    if (c->d_q) hipFree(c->d_q);
+    if (c->d_state) hipFree(c->d_state);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return MNW_OK;
+}
+
+int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return MNW_E_ARG;
+    if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (96ll << 20); return MNW_OK; }
+    if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
+    return fail(c, MNW_E_ARG, "unknown option");
+}
+
+// ---- scalars ------------------------------------------------------------------------------
+int64_t mnw_precision_needed(uint64_t max) {
+    int b = mnw::precision_needed(max);
+    return b < 0 ? INT64_MIN : b;            // int(-Inf) on amd64 (bit.go:20 with max+1 == 0)
+}
+
+int64_t mnw_array_bytes(int64_t bits, int64_t length) { return mnw::array_bytes(bits, length); }
+
+int64_t mnw_float_group_pixels(float low, float high, float dx) {   // writer.go:73
+    volatile float span = high - low;
+    volatile float r = span / dx;
+    double c = ceil((double)r);
+    if (!(c >= -9223372036854775808.0 && c < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)c;
+}
+
+// ---- timing -------------------------------------------------------------------------------
+int mnw_timing_enable(mnw_ctx* c, int on) { if (!c) return MNW_E_ARG; c->timing = on != 0; return MNW_OK; }
+
+static int collect_timing(mnw_ctx* c) {
+    for (auto& t : c->launches) {
+        float ms = 0;
+        hipEventSynchronize(t.stop);
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            c->acc[t.kernel].total_ms += ms;
+            c->acc[t.kernel].launches += 1;
+        }
+        c->event_pool.push_back(t.start);
+        c->event_pool.push_back(t.stop);
+    }
+    c->launches.clear();
+    return MNW_OK;
+}
+
+int mnw_timing_reset(mnw_ctx* c) {
+    if (!c) return MNW_E_ARG;
+    collect_timing(c);
+    memset(c->acc, 0, sizeof c->acc);
+    return MNW_OK;
+}
+
+int mnw_timing_get(mnw_ctx* c, mnw_kernel_time* out) {
+    if (!c || !out) return MNW_E_ARG;
+    collect_timing(c);
+    memcpy(out, c->acc, sizeof c->acc);
+    return MNW_OK;
+}
+
+// ---- batched device-pointer encode ----------------------------------------------------------
+int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* jobs, int njobs) {
+    if (!c || njobs < 0 || (njobs > 0 && !jobs)) return fail(c, MNW_E_ARG, "encode: bad arguments");
+    if (c->pending) return fail(c, MNW_E_ARG, "encode: a batch is already pending; call mnw_encode_blocks_finish");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (int i = 0; i < njobs; ++i)
+        if (!job_ok(jobs[i])) return fail(c, MNW_E_ARG, "encode: bad job (null/misaligned pointer, negative size or unknown kind)");
+    JobSlot* sl;
+    int rc = acquire_slot(c, njobs > 0 ? njobs : 1, &sl);
+    if (rc) return rc;
+
+    c->pend_jobs.assign(jobs, jobs + njobs);
+    c->pend_slot.assign(njobs, -1);
+    c->pend_host.assign(njobs, Meta{0, 0, 0, 0});
+    c->pend_stream = s;
+
+    // device slots: float jobs first, then int jobs, each in caller order
+    int nslot = 0, nfloat = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kind = pass == 0 ? MNW_FLOAT_GROUP : MNW_INT_GROUP;
+        for (int i = 0; i < njobs; ++i) {
+            const mnw_enc_job& j = jobs[i];
+            if (j.kind != kind) continue;
+            if (j.n == 0) continue;   // group.go:351, bit.go:152: empty block -> min 0, bits 0, no bytes
+            if (kind == MNW_FLOAT_GROUP && (j.pixels > 0x7fffffffll || j.pixels <= 0)) {
+                c->pend_host[i].status = mnw::kNeedsExact;   // 64-bit ring: exact path at finish
+                continue;
+            }
+            fill_enc(sl->h_jobs[nslot], j);
+            c->pend_slot[i] = nslot++;
+        }
+        if (pass == 0) nfloat = nslot;
+    }
+    if (nslot > 0) {
+        // group-relative tile numbering is assigned inside launch_encode_range's grouping; compute it here
+        for (int pass = 0; pass < 2; ++pass) {
+            const int j0 = pass == 0 ? 0 : nfloat, j1 = pass == 0 ? nfloat : nslot;
+            const int64_t esz = pass == 0 ? 4 : 8;
+            int g0 = j0;
+            while (g0 < j1) {
+                int g1 = g0; int64_t bytes = 0, tiles = 0;
+                while (g1 < j1 && (g1 == g0 || bytes + sl->h_jobs[g1].n * esz <= c->group_bytes)) {
+                    sl->h_jobs[g1].tile0 = tiles;
+                    bytes += sl->h_jobs[g1].n * esz;
+                    tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
+                    ++g1;
+                }
+                g0 = g1;
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot, s));
+        rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
+        if (rc) return rc;
+        rc = launch_encode_range(c, sl, s, nfloat, nslot, MNW_INT_GROUP);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta) * nslot, hipMemcpyDeviceToHost, s));
+    }
+    rc = release_slot(c, sl, s);
+    if (rc) return rc;
+    c->pending = true;
+    c->pend = sl;
+    return MNW_OK;
+}
+
+int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* meta) {
+    if (!c || !c->pending) return fail(c, MNW_E_ARG, "finish: no pending batch");
+    (void)stream;
+    hipStream_t s = c->pend_stream;
+    c->pending = false;
+    JobSlot* sl = c->pend;
+    c->pend = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int njobs = (int)c->pend_jobs.size();
+    std::vector<Meta> res(njobs);
+    for (int i = 0; i < njobs; ++i) res[i] = c->pend_slot[i] >= 0 ? sl->h_meta[c->pend_slot[i]] : c->pend_host[i];
+    int first = MNW_OK;
+    for (int i = 0; i < njobs; ++i) {
+        if (res[i].status == mnw::kNeedsExact) {
+            Meta m;
+            int rc = encode_exact_float(c, s, c->pend_jobs[i], &m);
+            if (rc) return rc;
+            res[i] = m;
+        }
+        if (res[i].status != 0 && first == MNW_OK) first = (int)res[i].status;
+    }
+    if (meta) memcpy(meta, res.data(), sizeof(Meta) * njobs);
+    if (first != MNW_OK) fail(c, first, mnw_strerror(first));
+    return first;
+}
+
+int mnw_encode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* jobs, int njobs, mnw_block_meta* meta) {
+    int rc = mnw_encode_blocks_async(c, stream, jobs, njobs);
+    if (rc) return rc;
+    return mnw_encode_blocks_finish(c, stream, meta);
+}
+
+// ---- batched device-pointer decode ----------------------------------------------------------
+int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, int njobs) {
+    if (!c || njobs < 0 || (njobs > 0 && !jobs)) return fail(c, MNW_E_ARG, "decode: bad arguments");
+    if (c->pending) return fail(c, MNW_E_ARG, "decode: an encode batch is pending");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    JobSlot* sl;
+    int rc = acquire_slot(c, njobs > 0 ? njobs : 1, &sl);
+    if (rc) return rc;
+    // three launch classes: float 32-bit path, float 64-bit path, int64
+    int cls_begin[4] = {0, 0, 0, 0};
+    int nslot = 0;
+    for (int cls = 0; cls < 3; ++cls) {
+        cls_begin[cls] = nslot;
+        int64_t tiles = 0;
+        for (int i = 0; i < njobs; ++i) {
+            const mnw_dec_job& j = jobs[i];
+            if (j.n < 0 || j.bits < 0 || j.bits > 64) return fail(c, MNW_E_ARG, "decode: bits outside 0..64 or negative n");
+            if (j.kind != MNW_INT_GROUP && j.kind != MNW_FLOAT_GROUP) return fail(c, MNW_E_ARG, "decode: unknown kind");
+            if (j.n == 0) continue;
+            if (!j.dst || (j.bits > 0 && !j.src)) return fail(c, MNW_E_ARG, "decode: null pointer");
+            if (j.src_len < mnw::array_bytes(j.bits, j.n) && j.bits > 0) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
+            int jc;
+            if (j.kind == MNW_INT_GROUP) jc = 2;
+            else {
+                const bool narrow = j.bits <= 32 && j.pixels <= 0x7fffffffll && j.min >= -0x80000000ll &&
+                                    j.min + (int64_t)((1ull << j.bits) - 1) <= 0x7fffffffll;
+                jc = narrow ? 0 : 1;
+            }
+            if (jc != cls) continue;
+            DevJob& d = sl->h_jobs[nslot++];
+            memset(&d, 0, sizeof d);
+            d.src = j.src; d.dst = j.dst; d.n = j.n; d.cap = j.src_len; d.pixels = j.pixels;
+            d.min = j.min; d.bits = (int32_t)j.bits; d.seed = j.seed; d.block = j.block;
+            d.low = j.low; d.high = j.high; d.kind = j.kind; d.periodic = j.periodic;
+            d.mode = mnw::kModeExplicit;
+            if (j.kind == MNW_FLOAT_GROUP) d.dxq = quant_dx(j.low, j.high, j.pixels);   // group.go:305-306
+            d.tile0 = tiles;
+            tiles += (j.n + mnw::kTile - 1) / mnw::kTile;
+        }
+    }
+    cls_begin[3] = nslot;
+    if (nslot == 0) return MNW_OK;
+    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+    for (int cls = 0; cls < 3; ++cls) {
+        const int j0 = cls_begin[cls], j1 = cls_begin[cls + 1];
+        if (j1 == j0) continue;
+        int64_t tiles = sl->h_jobs[j1 - 1].tile0 + (sl->h_jobs[j1 - 1].n + mnw::kTile - 1) / mnw::kTile;
+        const int grid = grid_for(c, tiles);
+        if (cls < 2) { ScopedTimer t(c, s, MNW_K_UNPACK_F32); mnw::launch_unpack_f32(s, grid, cls == 0, sl->d_jobs + j0, j1 - j0, tiles); }
+        else { ScopedTimer t(c, s, MNW_K_UNPACK_I64); mnw::launch_unpack_i64(s, grid, sl->d_jobs + j0, j1 - j0, tiles); }
+    }
+    HIPCHK(c, hipGetLastError());
+    return release_slot(c, sl, s);
+}
+
+// ---- raw bit.Array on device buffers ----------------------------------------------------------
+int mnw_pack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint64_t* x, int64_t n, int bits, uint8_t* out, int64_t cap) {
+    if (!c || n < 0 || bits < 0) return fail(c, MNW_E_ARG, "pack: bad arguments");
+    if (bits > 64) return fail(c, MNW_E_ARG, "Cannot pack more than 64 bits per element into a bit.Array");  // bit.go:85-87
+    if (n == 0 || bits == 0) return MNW_OK;
+    if (!x || !out || ((uintptr_t)out & 7)) return fail(c, MNW_E_ARG, "pack: null or misaligned pointer");
+    if (cap < mnw::array_bytes(bits, n)) return fail(c, MNW_E_BUFLEN, "pack: output shorter than ArrayBytes(bits, n)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    JobSlot* sl;
+    int rc = acquire_slot(c, 1, &sl);
+    if (rc) return rc;
+    DevJob& d = sl->h_jobs[0];
+    memset(&d, 0, sizeof d);
+    d.src = x; d.dst = out; d.n = n; d.cap = cap; d.kind = MNW_INT_GROUP;
+    d.mode = mnw::kModeExplicit; d.min = 0; d.bits = bits; d.tile0 = 0;
+    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob), hipMemcpyHostToDevice, s));
+    const int64_t tiles = (n + mnw::kTile - 1) / mnw::kTile;
+    { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid_for(c, tiles), sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
+    HIPCHK(c, hipGetLastError());
+    return release_slot(c, sl, s);
+}
+
+int mnw_unpack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint8_t* in, int64_t in_len, int bits, int64_t n, uint64_t* out) {
+    if (!c || n < 0 || bits < 0 || bits > 64) return fail(c, MNW_E_ARG, "unpack: bad arguments");
+    if (n == 0) return MNW_OK;
+    if (!out) return fail(c, MNW_E_ARG, "unpack: null pointer");
+    mnw_dec_job j;
+    memset(&j, 0, sizeof j);
+    j.src = in; j.dst = out; j.n = n; j.src_len = in_len; j.min = 0; j.bits = bits; j.kind = MNW_INT_GROUP;
+    return mnw_decode_blocks(c, stream, &j, 1);
+}
+
+// ---- host-pointer synchronous forms (cgo surface) ----------------------------------------------
+static int stage_in(mnw_ctx* c, const void* host, size_t bytes) {
+    int rc = ensure_dev(c, &c->d_in, &c->cap_in, bytes + 16);
+    if (rc) return rc;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(c->d_in, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return MNW_OK;
+}
+
+int mnw_pack_u64(mnw_ctx* c, const uint64_t* x, int64_t n, int bits, uint8_t* out, int64_t out_len) {
+    if (!c) return MNW_E_ARG;
+    if (n < 0 || bits < 0) return fail(c, MNW_E_ARG, "pack: bad arguments");
+    if (bits > 64) return fail(c, MNW_E_ARG, "Cannot pack more than 64 bits per element into a bit.Array");
+    if (out_len != mnw::array_bytes(bits, n)) return fail(c, MNW_E_BUFLEN, "bit.BufferedArray given buffer of the wrong length");  // bit.go:88-92
+    if (out_len == 0) return MNW_OK;
+    if (!x || !out) return fail(c, MNW_E_ARG, "pack: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = stage_in(c, x, (size_t)n * 8);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)out_len + 16);
+    if (rc) return rc;
+    rc = mnw_pack_u64_dev(c, c->stream, (const uint64_t*)c->d_in, n, bits, (uint8_t*)c->d_out, (int64_t)c->cap_out);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)out_len, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
+int mnw_unpack_u64(mnw_ctx* c, const uint8_t* in, int64_t in_len, int bits, int64_t n, uint64_t* out) {
+    if (!c) return MNW_E_ARG;
+    if (n < 0 || bits < 0 || bits > 64 || in_len < 0) return fail(c, MNW_E_ARG, "unpack: bad arguments");
+    if (n == 0) return MNW_OK;
+    if (!out || (bits > 0 && !in)) return fail(c, MNW_E_ARG, "unpack: null pointer");
+    if (in_len < mnw::array_bytes(bits, n)) return fail(c, MNW_E_BUFLEN, "unpack: stream shorter than ArrayBytes(bits, n)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)mnw::array_bytes(bits, n);
+    int rc = stage_in(c, in, nb);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)n * 8);
+    if (rc) return rc;
+    rc = mnw_unpack_u64_dev(c, c->stream, (const uint8_t*)c->d_in, (int64_t)nb, bits, n, (uint64_t*)c->d_out);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
+static int encode_host(mnw_ctx* c, int kind, const void* x, int64_t n, float low, float high, int64_t pixels,
+                       int periodic, int64_t* min, int64_t* bits, uint8_t* out, int64_t cap, int64_t* out_len) {
+    if (!c) return MNW_E_ARG;
+    if (n < 0 || cap < 0 || !min || !bits || !out_len) return fail(c, MNW_E_ARG, "encode: bad arguments");
+    *min = 0; *bits = 0; *out_len = 0;
+    if (n == 0) return MNW_OK;
+    if (!x) return fail(c, MNW_E_ARG, "encode: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t esz = kind == MNW_FLOAT_GROUP ? 4 : 8;
+    int rc = stage_in(c, x, (size_t)n * esz);
+    if (rc) return rc;
+    const int64_t worst = 8 * n;   // 64 bits per element
+    const int64_t dcap = cap < worst ? cap : worst;
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)dcap + 16);
+    if (rc) return rc;
+    mnw_enc_job j;
+    memset(&j, 0, sizeof j);
+    j.src = c->d_in; j.dst = c->d_out; j.n = n; j.cap = dcap; j.pixels = pixels; j.low = low; j.high = high;
+    j.kind = kind; j.periodic = periodic;
+    mnw_block_meta m;
+    rc = mnw_encode_blocks(c, c->stream, &j, 1, &m);
+    *min = m.min; *bits = m.bits;
+    if (rc) return rc;
+    *out_len = m.nbytes;
+    if (m.nbytes > 0) {
+        if (!out) return fail(c, MNW_E_ARG, "encode: null output");
+        HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)m.nbytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MNW_OK;
+}
+
+int mnw_int_encode(mnw_ctx* c, const int64_t* x, int64_t n, int64_t* min, int64_t* bits, uint8_t* out, int64_t cap, int64_t* out_len) {
+    return encode_host(c, MNW_INT_GROUP, x, n, 0, 0, 0, 0, min, bits, out, cap, out_len);
+}
+
+int mnw_float_encode(mnw_ctx* c, const float* x, int64_t n, float low, float high, int64_t pixels, int periodic,
+                     int64_t* min, int64_t* bits, uint8_t* out, int64_t cap, int64_t* out_len) {
+    return encode_host(c, MNW_FLOAT_GROUP, x, n, low, high, pixels, periodic, min, bits, out, cap, out_len);
+}
+
+static int decode_host(mnw_ctx* c, int kind, const uint8_t* in, int64_t in_len, int64_t min, int64_t bits, float low,
+                       float high, int64_t pixels, int periodic, uint64_t seed, uint64_t block, int64_t n, void* out) {
+    if (!c) return MNW_E_ARG;
+    if (n < 0 || bits < 0 || bits > 64 || in_len < 0) return fail(c, MNW_E_ARG, "decode: bad arguments");
+    if (n == 0) return MNW_OK;
+    if (!out || (bits > 0 && !in)) return fail(c, MNW_E_ARG, "decode: null pointer");
+    const int64_t nb = bits == 0 ? 0 : mnw::array_bytes(bits, n);
+    if (in_len < nb) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = stage_in(c, in, (size_t)nb);
+    if (rc) return rc;
+    const size_t esz = kind == MNW_FLOAT_GROUP ? 4 : 8;
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)n * esz);
+    if (rc) return rc;
+    mnw_dec_job j;
+    memset(&j, 0, sizeof j);
+    j.src = c->d_in; j.dst = c->d_out; j.n = n; j.src_len = nb; j.min = min; j.bits = bits; j.pixels = pixels;
+    j.low = low; j.high = high; j.kind = kind; j.periodic = periodic; j.seed = seed; j.block = block;
+    rc = mnw_decode_blocks(c, c->stream, &j, 1);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
+int mnw_int_decode(mnw_ctx* c, const uint8_t* in, int64_t in_len, int64_t min, int64_t bits, int64_t n, int64_t* out) {
+    return decode_host(c, MNW_INT_GROUP, in, in_len, min, bits, 0, 0, 0, 0, 0, 0, n, out);
+}
+
+int mnw_float_decode(mnw_ctx* c, const uint8_t* in, int64_t in_len, int64_t min, int64_t bits, float low, float high,
+                     int64_t pixels, int periodic, uint64_t seed, uint64_t block, int64_t n, float* out) {
+    return decode_host(c, MNW_FLOAT_GROUP, in, in_len, min, bits, low, high, pixels, periodic, seed, block, n, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// mnw_common.h -- types and scalar helpers shared by the HIP kernels and the C-ABI host code.
+// Product code: written for gfx950 (MI355X) only; never includes anything from oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MNW_HD __host__ __device__ __forceinline__
+
+namespace mnw {
+
+// Launch geometry.  A tile is the unit of work of one 256-thread workgroup iteration; it is a
+// multiple of 64 elements so every tile's packed output starts on a 64-bit word of the block's
+// stream (64 elements at b bits = b whole words).
+constexpr int kThreads = 256;
+constexpr int kTile = 2048;               // elements per tile (8 per thread)
+constexpr int kStatSlots = 64;            // per-job stats records, one 64-B line each
+constexpr int kStatWords = 8;             // uint64 per record
+
+// device-side job record (host fills it from mnw_enc_job / mnw_dec_job)
+struct DevJob {
+    const void* src;
+    void* dst;
+    int64_t n;
+    int64_t cap;         // encode: capacity of dst; decode: src_len
+    int64_t pixels;
+    int64_t tile0;       // first tile of this job in the launch-wide tile numbering
+    int64_t min;         // decode / explicit pack: intGroup.mins[b]
+    uint64_t seed;       // decode dither key
+    uint64_t block;      // decode dither key
+    float low, high;
+    float dxq;           // (high-low)/float32(pixels), IEEE float32, computed on the host
+    float hf;            // smallest float32 >= pixels/2 (splits the ring for the periodic stats)
+    int32_t kind;        // MNW_INT_GROUP / MNW_FLOAT_GROUP
+    int32_t periodic;
+    int32_t bits;        // decode / explicit pack
+    int32_t mode;        // kModeStats: width from the reduce pass; kModeExplicit: (min,bits) given
+};
+
+constexpr int kModeStats = 0;
+constexpr int kModeExplicit = 1;
+
+// per-block result, same layout as mnw_block_meta
+struct Meta {
+    int64_t min, bits, nbytes, status;
+};
+
+// internal status: the block needs the exact sequential path (out-of-range / NaN / huge values,
+// whose periodicMin result depends on element order, group.go:384-409)
+constexpr int64_t kNeedsExact = 100;
+
+// order-preserving map int64 -> uint64 so that zero-initialised memory is the identity of max
+MNW_HD uint64_t bias(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
+MNW_HD int64_t unbias(uint64_t u) { return (int64_t)(u ^ 0x8000000000000000ull); }
+
+// ---- Go's math.Frexp / Log / Log2 (go/bit/bit.go:20 calls math.Log2) -----------------------
+// Restated from the Go standard library's published algorithm (log.go = FreeBSD e_log.c).
+// Needed bit-for-bit only for max >= 2^48: below that ceil(log2(max+1)) is the bit length.
+MNW_HD double go_frexp_pos(double x, int* e) {   // x finite, > 0, normal (x >= 1 here)
+    union { double d; uint64_t u; } c;
+    c.d = x;
+    *e = (int)((c.u >> 52) & 0x7ff) - 1022;
+    c.u = (c.u & ~(0x7ffull << 52)) | (1022ull << 52);
+    return c.d;
+}
+
+MNW_HD double go_log_frac(double x) {            // x in [0.5, 1)
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01;
+    const double L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01;
+    const double L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01;
+    const double L7 = 1.479819860511658591e-01;
+    double f1 = x;
+    int ki = 0;
+    if (f1 < 0.70710678118654752440) { f1 *= 2; ki = -1; }
+    double f = f1 - 1;
+    double k = (double)ki;
+    double s = f / (2 + f);
+    double s2 = s * s;
+    double s4 = s2 * s2;
+    double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    double R = t1 + t2;
+    double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+// bit.PrecisionNeeded (bit.go:19-21).  Returns -1 for max == 2^64-1, where Go computes
+// int(ceil(log2(0))) = int(-Inf): out of domain (MNW_E_DOMAIN).
+MNW_HD int precision_needed(uint64_t max) {
+    if (max == ~0ull) return -1;
+    uint64_t m1 = max + 1;
+    if (m1 <= (1ull << 48)) {                    // exact region: bit length of max
+        int b = 0;
+        while (b < 64 && (max >> b) != 0) b++;
+        return b;
+    }
+    double x = (double)m1;                       // uint64 -> float64, round to nearest even
+    int e;
+    double frac = go_frexp_pos(x, &e);
+    double l2;
+    if (frac == 0.5) l2 = (double)(e - 1);
+    else l2 = go_log_frac(frac) * 1.44269504088896340736 + (double)e;
+    // ceil of a value in [48, 64]
+    int c = (int)l2;
+    if ((double)c < l2) c++;
+    return c;
+}
+
+MNW_HD int64_t array_bytes(int64_t bits, int64_t n) { return (bits * n + 7) / 8; }
+
+// ---- dither: counter-based uniform deviate for floatGroup.readData (DESIGN.md "Dither") -----
+MNW_HD uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+MNW_HD uint64_t dither_key(uint64_t seed, uint64_t block, uint64_t i_hi) {
+    return mix64(seed + 0x9E3779B97F4A7C15ull * (block + 1) + 0xD1B54A32D192ED03ull * i_hi);
+}
+MNW_HD uint32_t dither_bits(uint32_t i_lo, uint32_t ka, uint32_t kb) {
+    uint32_t x = i_lo ^ ka;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x ^ kb;
+}
+
+}  // namespace mnw
