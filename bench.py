@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- minnow column quantize + bit-pack hot path on MI355X.
+
+A step = one pass of the hot path over one synthetic float32 position column (BASELINE.json
+configs[1]: 1e8 particles, FloatGroup low=0 high=250 dx=0.001 -> pixels=250000, Gaussian positions
+wrapped into [0,250)): encode every block of the column (reduce + pack kernels)
+and decode it back (unpack kernel), inputs and outputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); blocks shard
+embarrassingly -- every rank owns its own column, no data-path collective -- so the
+scaling is weak and `value` is the whole-job aggregate.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+LOW, HIGH, DX = 0.0, 250.0, 0.001
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--particles", type=int, default=10**8)
+    p.add_argument("--block", type=int, default=2**24, help="elements per block (unit of GPU dispatch)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--group-bytes", type=int, default=0)
+    return p.parse_args()
+
+
+def make_column(n, device, seed):
+    """x = wrap(125 + 20*N(0,1)) into [0,250), Philox (torch CUDA generator), SURVEY 8d C2."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.randn(n, device=device, dtype=torch.float32, generator=g)
+    x.mul_(20.0).add_(125.0)
+    x = torch.remainder(x, 250.0)
+    x[x >= 250.0] = 0.0
+    return x.contiguous()
+
+
+def cpu_baseline(mnw_pixels, n_threads):
+    """The oracle's LITERAL byte-wise restatement of go/bit + group.go (kind "port": the Go
+    reference cannot be built in this image) timed on this host's cores, on a bounded sample of the
+    same workload: each thread encodes and decodes its own blocks of 2^22 elements."""
+    from oracle import oracle as orc
+
+    orc.build()
+    orc.lib()
+    blk, per_thread = 1 << 22, 8
+    rng = np.random.default_rng(0xACEDAD)
+    x = np.mod(125 + 20 * rng.standard_normal(blk), 250).astype(np.float32)
+    x[x >= np.float32(250.0)] = 0.0
+    u = orc.dither(1, 0, blk)
+    orc.float_encode(x[:4096], LOW, HIGH, mnw_pixels, True, literal=True)  # warm the library
+
+    def work():
+        for _ in range(per_thread):
+            mn, bits, data = orc.float_encode(x, LOW, HIGH, mnw_pixels, True, literal=True)
+            orc.float_decode(data, mn, bits, LOW, HIGH, mnw_pixels, True, blk, u=u, literal=True)
+
+    threads = [threading.Thread(target=work) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    total_bytes = 4.0 * blk * per_thread * n_threads
+    return {
+        "value": total_bytes / dt / 1e9, "unit": "GB/s", "cores": n_threads, "kind": "port",
+        "sample": "%d threads x %d blocks of 2^22 float32 (same Gaussian column shape), encode+decode "
+                  "with the literal byte-wise restatement of go/bit + group.go, %.1f s" % (n_threads, per_thread, dt),
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import minnow_amd as mnw
+    from minnow_amd import build as mnw_build
+
+    if rank == 0:
+        mnw_build.build()
+    if dist is not None:
+        dist.barrier()
+    if mnw.device_count() < 1:
+        raise RuntimeError("bench.py needs a GPU: libminnow_hip has no CPU fallback")
+
+    pixels = mnw.float_group_pixels(LOW, HIGH, DX)
+    N, B = a.particles, a.block
+    nblk = (N + B - 1) // B
+    x = make_column(N, device, 0xACEDAD + rank)
+    y = torch.empty_like(x)
+    # packed output: one 8-byte aligned slot per block, worst case 32 bits per element
+    slot = (4 * B + 15) // 16 * 16
+    packed = torch.zeros(nblk * slot, dtype=torch.uint8, device=device)
+    ctx = mnw.Context(local_rank)
+    if a.group_bytes:
+        ctx.set_option("group_bytes", a.group_bytes)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    enc_jobs = [mnw.EncJob(x.data_ptr() + 4 * k * B, packed.data_ptr() + k * slot, min(B, N - k * B), slot,
+                           mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1) for k in range(nblk)]
+
+    def dec_jobs_from(metas):
+        return [mnw.DecJob(packed.data_ptr() + k * slot, y.data_ptr() + 4 * k * B, enc_jobs[k].n, metas[k].nbytes,
+                           metas[k].min, metas[k].bits, mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1, seed=1, block=k)
+                for k in range(nblk)]
+
+    def step():
+        metas = ctx.encode_blocks(enc_jobs, stream=stream)      # returns with (min, bits, nbytes) per block
+        ctx.decode_blocks(dec_jobs_from(metas), stream=stream)
+        return metas
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        metas = step()
+    sync_all()
+
+    # ---- timed region: exactly K steps --------------------------------------------------------
+    timing = not a.no_kernel_timing
+    if timing:
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        metas = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ktimes = ctx.timing_get() if timing else {}
+    if timing:
+        ctx.timing_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # separate, un-instrumented encode-only / decode-only timings (reported, not `value`)
+    def time_only(fn, reps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+
+    reps = max(3, min(a.steps, 10))
+    t_enc = time_only(lambda: ctx.encode_blocks(enc_jobs, stream=stream), reps)
+    dj = dec_jobs_from(metas)
+    t_dec = time_only(lambda: ctx.decode_blocks(dj, stream=stream), reps)
+
+    # ---- sanity on the result of the last step (cheap, outside the timed region) -----------------
+    bits = sorted(set(m.bits for m in metas))
+    assert all(m.status == 0 for m in metas)
+    d = (y[: 1 << 20].double() - x[: 1 << 20].double()).abs()
+    d = torch.minimum(d, 250.0 - d)
+    assert float(d.max()) <= DX * 1.01 + 1e-4, "round trip outside the reference tolerance"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    in_bytes = 4.0 * N
+    packed_bytes = float(sum(m.nbytes for m in metas))
+    ms_per_step = dt / a.steps * 1e3
+    value = world * in_bytes / (dt / a.steps) / 1e9
+    out = {
+        "metric": "encode+decode GB/s (input)", "value": value, "unit": "GB/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32->u32 fixed point (f32 sub/div, integer pack)", "data": "synthetic",
+        "config": {"workload": "configs[1]: single float32 position column, %d particles, FloatGroup "
+                               "low=0 high=250 dx=0.001 (pixels=%d), blocks of %d, encode+decode round trip"
+                               % (N, pixels, B),
+                   "blocks_per_gpu": nblk, "bits": bits, "parallelism": "blocks sharded per GPU, no collective"},
+        "pct_hbm_peak": 100.0 * (in_bytes * 2 + 2 * packed_bytes) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
+        "encode_GBps_input": in_bytes / t_enc / 1e9, "decode_GBps_output": in_bytes / t_dec / 1e9,
+        "compressed_bits_per_elt": 8.0 * packed_bytes / N,
+    }
+
+    # ---- roofline: algorithmic bytes / HIP-event kernel time, per launch ---------------------------
+    if timing and ktimes:
+        steps = a.steps
+        red, pk, up = ktimes.get("k_reduce_f32"), ktimes.get("k_pack_f32"), ktimes.get("k_unpack_f32")
+        enc_alg = in_bytes + packed_bytes                     # (4 + b/8) B/elt, one read + one write
+        dec_alg = packed_bytes + in_bytes                     # (b/8 + 4) B/elt
+        enc_ms = (red["total_ms"] + pk["total_ms"]) / steps   # device time of one column encode
+        dec_ms = up["total_ms"] / steps
+        kern = []
+        for name, kt, alg in (("k_reduce_f32", red, None), ("k_pack_f32", pk, None), ("k_unpack_f32", up, dec_alg)):
+            if kt and kt["launches"]:
+                kern.append({"kernel": name, "launches": kt["launches"], "avg_us": 1e3 * kt["total_ms"] / kt["launches"]})
+        enc_ach = enc_alg / (enc_ms * 1e-3) / 1e9
+        dec_ach = dec_alg / (dec_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_reduce_f32+k_pack_f32 (float encode = two launches per block group)",
+            "achieved": enc_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc_ach / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_elt": (in_bytes + packed_bytes) / N,
+            "elements_per_launch": N / (pk["launches"] / steps),
+            "avg_launch_us": {"k_reduce_f32": 1e3 * red["total_ms"] / red["launches"],
+                              "k_pack_f32": 1e3 * pk["total_ms"] / pk["launches"]},
+        }
+        out["roofline_decode"] = {
+            "bound": "hbm", "kernel": "k_unpack_f32", "achieved": dec_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": dec_ach / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_elt": dec_alg / N,
+            "avg_launch_us": 1e3 * up["total_ms"] / up["launches"],
+        }
+        out["kernels"] = kern
+
+    if world == 1 and not a.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
+        out["cpu_baseline"] = cpu_baseline(pixels, max(1, min(16, ncpu)))
+
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

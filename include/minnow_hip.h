@@ -96,12 +96,12 @@ int mnw_float_decode(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int64_t mi
 /* ---- device-pointer, batched forms: per-column blocks as the unit of GPU dispatch --------------
  * src/dst are DEVICE pointers (hipMalloc / torch tensors).  One call enqueues every block of the
  * batch on `stream`; blocks are independent (group.go:242-255 depends on one block only).  The
- * packed stream of block k is written at dst (8-byte aligned, capacity cap bytes); its exact
+ * packed stream of block k is written at dst (16-byte aligned, capacity cap bytes); its exact
  * length comes back in meta[k].nbytes, which is what blockIndex.addBlock receives
  * (block_index.go:16-23). */
 typedef struct mnw_enc_job {
     const void *src;     /* device: float32[n] (MNW_FLOAT_GROUP) or int64[n] (MNW_INT_GROUP) */
-    void *dst;           /* device: packed stream, 8-byte aligned */
+    void *dst;           /* device: packed stream, 16-byte aligned */
     int64_t n;           /* elements in the block */
     int64_t cap;         /* bytes available at dst */
     int64_t pixels;      /* float groups: floatGroup.pixels */
@@ -147,7 +147,7 @@ int mnw_encode_blocks_finish(mnw_ctx *ctx, mnw_stream_t stream, mnw_block_meta *
 int mnw_decode_blocks(mnw_ctx *ctx, mnw_stream_t stream, const mnw_dec_job *jobs, int njobs);
 
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
- * dst of pack must hold ArrayBytes(bits, n) rounded up to 8 bytes. */
+ * out of pack must be 16-byte aligned. */
 int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
                      uint8_t *out, int64_t cap);
 int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int64_t in_len, int bits,
@@ -163,6 +163,7 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_PACK_I64    3
 #define MNW_K_UNPACK_F32  4
 #define MNW_K_UNPACK_I64  5
+#define MNW_K_ENCODE_F32  6   /* fused float encode: reduce + pack of a whole batch in one persistent launch */
 #define MNW_K_COUNT       8
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
@@ -173,8 +174,11 @@ int mnw_timing_reset(mnw_ctx *ctx);
 int mnw_timing_get(mnw_ctx *ctx, mnw_kernel_time *out /* [MNW_K_COUNT] */);
 const char *mnw_kernel_name(int kernel_id);
 
-/* Tunables (0 = default).  group_bytes: blocks are launched in groups whose input is at most this
- * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM. */
+/* Tunables (0 = default).  group_bytes: blocks are processed in groups whose input is at most this
+ * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM.
+ * fused: 1 = float batches run as one persistent launch (k_encode_f32), 0 (default) = one reduce and one
+ *        pack launch per group.
+ * grid_cap: upper bound on workgroups per launch. */
 int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus

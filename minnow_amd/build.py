@@ -17,7 +17,7 @@ HEADERS = ["mnw_common.h", os.path.join("..", "..", "include", "minnow_hip.h")]
 FLAGS = [
     "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero",
-    "-fno-fast-math", "-x", "hip", "-Wall", "-Wno-unused-function",
+    "-fno-fast-math", "-x", "hip", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
 ]
 
 

@@ -17,7 +17,7 @@ FLOAT_GROUP = 11   # go/group.go:23
 class EncJob:
     """One block to encode: what Writer.Data hands to group.writeData (writer.go:90-103)."""
     src: int               # device pointer: float32[n] or int64[n]
-    dst: int               # device pointer, 8-byte aligned
+    dst: int               # device pointer, 16-byte aligned
     n: int
     cap: int
     kind: int = FLOAT_GROUP

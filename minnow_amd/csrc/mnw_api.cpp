@@ -12,10 +12,13 @@
 #include <vector>
 
 namespace mnw {
-void launch_reduce_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
+void launch_reduce_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*, void*, Meta*);
+size_t job_sync_bytes();
 void launch_reduce_i64(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
-void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
+void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
+void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
+int encode_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
@@ -34,6 +37,7 @@ struct TimedLaunch {
 };
 
 constexpr int kSlots = 3;
+constexpr int kSyncPad = 32;      // keeps the abort flag on its own 128-byte line
 struct JobSlot {
     int cap = 0;
     DevJob* d_jobs = nullptr;
@@ -41,6 +45,14 @@ struct JobSlot {
     uint64_t* d_stats = nullptr;
     Meta* d_meta = nullptr;
     Meta* h_meta = nullptr;       // pinned
+    int64_t* d_gtile = nullptr;   // fused encode: group boundaries in the batch-wide tile numbering
+    int64_t* h_gtile = nullptr;   // pinned
+    int* d_gjob = nullptr;        // fused encode: first job of each group
+    int* h_gjob = nullptr;        // pinned
+    uint8_t* d_sync = nullptr;    // per-job arrival count + published descriptor word (mnw::JobSync), then
+                                  // kSyncPad words whose first is the fused launch's abort flag
+    uint32_t* h_sync = nullptr;   // pinned: abort flag read back with the metadata
+    size_t sync_stride = 64;
     hipEvent_t consumed = nullptr;
     bool in_flight = false;
 };
@@ -76,8 +88,13 @@ struct mnw_ctx {
     hipStream_t pend_stream = nullptr;
 
     // options
-    int64_t group_bytes = 96ll << 20;
+    int64_t group_bytes = 1ll << 40;   // two-kernel path: all blocks of a batch in one reduce + one pack launch
     int grid_cap = 0;
+    int fused = 0;               // float encode as one persistent launch per batch (k_encode_f32): opt-in, see DESIGN.md
+    int fused_blocks_per_cu = 0; // co-resident workgroups of k_encode_f32 per CU (occupancy query)
+    int64_t fused_aborts = 0;    // fused launches that fell back to the two-kernel path
+    int pend_nfloat = 0;         // device slots [0, pend_nfloat) of the pending batch are float jobs
+    bool pend_fused = false;
 
     // timing
     bool timing = false;
@@ -105,7 +122,11 @@ int fail(mnw_ctx* c, int status, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 void free_slot(JobSlot& sl) {
-    if (sl.d_jobs) { hipFree(sl.d_jobs); hipFree(sl.d_stats); hipFree(sl.d_meta); hipHostFree(sl.h_jobs); hipHostFree(sl.h_meta); }
+    if (sl.d_jobs) {
+        hipFree(sl.d_jobs); hipFree(sl.d_stats); hipFree(sl.d_meta); hipHostFree(sl.h_jobs); hipHostFree(sl.h_meta);
+        hipFree(sl.d_gtile); hipHostFree(sl.h_gtile); hipFree(sl.d_gjob); hipHostFree(sl.h_gjob);
+        hipFree(sl.d_sync); hipHostFree(sl.h_sync);
+    }
     sl.d_jobs = nullptr; sl.cap = 0;
 }
 
@@ -126,9 +147,23 @@ int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
         HIPCHK(c, hipMalloc((void**)&sl.d_meta, sizeof(Meta) * cap));
         HIPCHK(c, hipHostMalloc((void**)&sl.h_jobs, sizeof(DevJob) * cap, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&sl.d_gtile, sizeof(int64_t) * (cap + 1)));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_gtile, sizeof(int64_t) * (cap + 1), hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&sl.d_gjob, sizeof(int) * (cap + 1)));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_gjob, sizeof(int) * (cap + 1), hipHostMallocDefault));
+        sl.sync_stride = mnw::job_sync_bytes();
+        HIPCHK(c, hipMalloc((void**)&sl.d_sync, sl.sync_stride * cap + sizeof(uint32_t) * kSyncPad));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_sync, sizeof(uint32_t) * kSyncPad, hipHostMallocDefault));
         sl.cap = cap;
     }
     *out = &sl;
+    return MNW_OK;
+}
+
+uint32_t* abort_ptr(JobSlot* sl) { return (uint32_t*)(sl->d_sync + sl->sync_stride * sl->cap); }
+int clear_sync(mnw_ctx* c, JobSlot* sl, hipStream_t s, int njobs) {
+    HIPCHK(c, hipMemsetAsync(sl->d_sync, 0, sl->sync_stride * njobs, s));
+    HIPCHK(c, hipMemsetAsync(abort_ptr(sl), 0, sizeof(uint32_t) * kSyncPad, s));
     return MNW_OK;
 }
 
@@ -163,16 +198,44 @@ struct ScopedTimer {   // event pair around one kernel launch, on the launch's o
     ~ScopedTimer() { if (on) { hipEventRecord(t.stop, s); c->launches.push_back(t); } }
 };
 
+// the pack pass is LDS-bound at 4 workgroups per CU; more workgroups than that only queue
+int pack_grid_for(mnw_ctx* c, int64_t tiles) {
+    int cap = c->grid_cap > 0 ? c->grid_cap : c->cus * 4;
+    return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
 int grid_for(mnw_ctx* c, int64_t tiles) {
     int cap = c->grid_cap > 0 ? c->grid_cap : c->cus * 8;
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
 }
 
-// smallest float32 >= pixels/2 (the float split point of the reduce pass)
-float ceil_f32_of(int64_t h) {
-    float f = (float)h;                  // round to nearest
-    if ((double)f < (double)h) f = nextafterf(f, INFINITY);
+// IEEE float32 quantize step of group.go:318-319 on the host (same arithmetic as the kernels)
+float host_quant_floor(float x, float low, float dx) {
+    volatile float t = x - low;
+    volatile float r = t / dx;
+    return floorf(r);
+}
+
+uint32_t host_fkey(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+float host_funkey(uint32_t k) {
+    uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu);
+    float f; memcpy(&f, &u, 4);
     return f;
+}
+
+// least float32 x (in the total order -inf .. +inf) whose quantized value is >= h.  q(x) is monotone
+// in x for dx > 0, so a bisection over the ordered bit patterns finds it in 32 steps.
+float split_point(float low, float dx, int64_t h) {
+    uint32_t lo = host_fkey(-INFINITY), hi = host_fkey(INFINITY);   // P(lo) false, P(hi) true
+    if ((double)host_quant_floor(-INFINITY, low, dx) >= (double)h) return -INFINITY;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((double)host_quant_floor(host_funkey(mid), low, dx) >= (double)h) hi = mid; else lo = mid;
+    }
+    return host_funkey(hi);
 }
 
 // (high-low)/float32(pixels) in IEEE float32, group.go:316
@@ -183,11 +246,17 @@ float quant_dx(float low, float high, int64_t pixels) {
     return dx;
 }
 
+// the reduce pass relies on q(x) being monotone non-decreasing: dx must be positive and finite
+bool float_fast_ok(const mnw_enc_job& j) {
+    const float dx = quant_dx(j.low, j.high, j.pixels);
+    return dx > 0.0f && dx < INFINITY && fabsf(j.low) < INFINITY;
+}
+
 bool job_ok(const mnw_enc_job& j) {
     if (j.n < 0 || j.cap < 0) return false;
     if (j.kind != MNW_INT_GROUP && j.kind != MNW_FLOAT_GROUP) return false;
     if (j.n > 0 && (!j.src || (!j.dst && j.cap > 0))) return false;
-    if (((uintptr_t)j.dst & 7) != 0) return false;
+    if (((uintptr_t)j.dst & 15) != 0) return false;
     if (j.n > (1ll << 47)) return false;
     return true;
 }
@@ -199,7 +268,8 @@ void fill_enc(DevJob& d, const mnw_enc_job& j) {
     d.mode = mnw::kModeStats;
     if (j.kind == MNW_FLOAT_GROUP) {
         d.dxq = quant_dx(j.low, j.high, j.pixels);
-        d.hf = ceil_f32_of(j.pixels / 2);
+        d.rdx = 1.0 / (double)d.dxq;
+        d.xh = split_point(j.low, d.dxq, j.pixels / 2);
     }
 }
 
@@ -220,8 +290,9 @@ int launch_encode_range(mnw_ctx* c, JobSlot* sl, hipStream_t s, int j0, int j1, 
             const int grid = grid_for(c, tiles);
             uint64_t* st = sl->d_stats + (size_t)g0 * mnw::kStatSlots * mnw::kStatWords;
             if (kind == MNW_FLOAT_GROUP) {
-                { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st); }
-                { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sl->d_meta + g0); }
+                void* sy = sl->d_sync + sl->sync_stride * g0;
+                { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sy, sl->d_meta + g0); }
+                { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, pack_grid_for(c, tiles), sl->d_jobs + g0, g1 - g0, tiles, sy); }
             } else {
                 { ScopedTimer t(c, s, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st); }
                 { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sl->d_meta + g0); }
@@ -230,6 +301,46 @@ int launch_encode_range(mnw_ctx* c, JobSlot* sl, hipStream_t s, int j0, int j1, 
         }
         g0 = g1;
     }
+    return MNW_OK;
+}
+
+// One persistent launch for all float jobs [0, nfloat) of the slot (k_encode_f32).  Groups follow
+// the same rule as launch_encode_range; tile0 here is batch-wide, not group relative.
+int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat) {
+    if (c->fused_blocks_per_cu == 0) {
+        int occ = mnw::encode_f32_blocks_per_cu();
+        // the occupancy API can over-report by one block per CU for SGPR-heavy kernels
+        // (MI355X_MICROARCH.md "Residency"): never ask for more than 4 (the LDS bound)
+        c->fused_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);
+    }
+    if (c->fused_blocks_per_cu < 1) return fail(c, MNW_E_HIP, "occupancy query failed for k_encode_f32");
+    int ng = 0;
+    int64_t tiles = 0;
+    int g0 = 0;
+    while (g0 < nfloat) {
+        int g1 = g0;
+        int64_t bytes = 0;
+        sl->h_gtile[ng] = tiles;
+        sl->h_gjob[ng] = g0;
+        ++ng;
+        while (g1 < nfloat && (g1 == g0 || bytes + sl->h_jobs[g1].n * 4 <= c->group_bytes)) {
+            bytes += sl->h_jobs[g1].n * 4;
+            tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
+            ++g1;
+        }
+        g0 = g1;
+    }
+    sl->h_gtile[ng] = tiles;
+    sl->h_gjob[ng] = nfloat;
+    if (tiles == 0) return MNW_OK;
+    HIPCHK(c, hipMemcpyAsync(sl->d_gtile, sl->h_gtile, sizeof(int64_t) * (ng + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(sl->d_gjob, sl->h_gjob, sizeof(int) * (ng + 1), hipMemcpyHostToDevice, s));
+    int grid = c->cus * c->fused_blocks_per_cu;
+    if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
+    { ScopedTimer t(c, s, MNW_K_ENCODE_F32);
+      mnw::launch_encode_f32(s, grid, sl->d_jobs, nfloat, sl->d_gtile, sl->d_gjob, ng, sl->d_stats, sl->d_sync, abort_ptr(sl), sl->d_meta); }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sl->h_sync, abort_ptr(sl), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return MNW_OK;
 }
 
@@ -244,11 +355,13 @@ int encode_one_sync(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, int mode,
     d.mode = mode; d.min = emin; d.bits = ebits; d.tile0 = 0;
     HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords, s));
+    rc = clear_sync(c, sl, s, 1);
+    if (rc) return rc;
     const int64_t tiles = (job.n + mnw::kTile - 1) / mnw::kTile;
     const int grid = grid_for(c, tiles);
     if (job.kind == MNW_FLOAT_GROUP) {
-        { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats); }
-        { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
+        { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_sync, sl->d_meta); }
+        { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, pack_grid_for(c, tiles), sl->d_jobs, 1, tiles, sl->d_sync); }
     } else {
         if (mode == mnw::kModeStats) { ScopedTimer t(c, s, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats); }
         { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
@@ -327,6 +440,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_PACK_I64: return "k_pack_i64";
         case MNW_K_UNPACK_F32: return "k_unpack_f32";
         case MNW_K_UNPACK_I64: return "k_unpack_i64";
+        case MNW_K_ENCODE_F32: return "k_encode_f32";
         default: return "";
     }
 }
@@ -367,7 +481,8 @@ int mnw_ctx_destroy(mnw_ctx* c) {
 
 int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return MNW_E_ARG;
-    if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (96ll << 20); return MNW_OK; }
+    if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (1ll << 40); return MNW_OK; }
+    if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
     return fail(c, MNW_E_ARG, "unknown option");
 }
@@ -445,7 +560,7 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
             const mnw_enc_job& j = jobs[i];
             if (j.kind != kind) continue;
             if (j.n == 0) continue;   // group.go:351, bit.go:152: empty block -> min 0, bits 0, no bytes
-            if (kind == MNW_FLOAT_GROUP && (j.pixels > 0x7fffffffll || j.pixels <= 0)) {
+            if (kind == MNW_FLOAT_GROUP && (j.pixels > 0x7fffffffll || j.pixels <= 0 || !float_fast_ok(j))) {
                 c->pend_host[i].status = mnw::kNeedsExact;   // 64-bit ring: exact path at finish
                 continue;
             }
@@ -471,9 +586,25 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
                 g0 = g1;
             }
         }
-        HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+        const bool fused = c->fused && nfloat > 0;
+        if (fused) {
+            // the fused launch numbers the tiles of the float jobs batch-wide (the int jobs keep the
+            // group-relative numbering assigned above)
+            int64_t tiles = 0;
+            for (int k = 0; k < nfloat; ++k) { sl->h_jobs[k].tile0 = tiles; tiles += (sl->h_jobs[k].n + mnw::kTile - 1) / mnw::kTile; }
+        }
         HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot, s));
-        rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
+        rc = clear_sync(c, sl, s, nslot);
+        if (rc) return rc;
+        c->pend_fused = fused;
+        c->pend_nfloat = nfloat;
+        if (fused) {
+            HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+            rc = launch_encode_fused(c, sl, s, nfloat);
+        } else {
+            HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+            rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
+        }
         if (rc) return rc;
         rc = launch_encode_range(c, sl, s, nfloat, nslot, MNW_INT_GROUP);
         if (rc) return rc;
@@ -496,6 +627,30 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(s));
     const int njobs = (int)c->pend_jobs.size();
+    if (c->pend_fused && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
+        // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
+        // part of the GPU): rerun the float jobs through the two-kernel path.  Still the GPU path.
+        c->fused_aborts++;
+        for (int k = 0, g0 = 0; g0 < c->pend_nfloat; ) {   // group-relative tile numbering again
+            (void)k;
+            int g1 = g0; int64_t bytes = 0, tiles = 0;
+            while (g1 < c->pend_nfloat && (g1 == g0 || bytes + sl->h_jobs[g1].n * 4 <= c->group_bytes)) {
+                sl->h_jobs[g1].tile0 = tiles;
+                bytes += sl->h_jobs[g1].n * 4;
+                tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
+                ++g1;
+            }
+            g0 = g1;
+        }
+        HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * c->pend_nfloat, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * c->pend_nfloat, s));
+        int rc = clear_sync(c, sl, s, c->pend_nfloat);
+        if (rc) return rc;
+        rc = launch_encode_range(c, sl, s, 0, c->pend_nfloat, MNW_FLOAT_GROUP);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta) * c->pend_nfloat, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
     std::vector<Meta> res(njobs);
     for (int i = 0; i < njobs; ++i) res[i] = c->pend_slot[i] >= 0 ? sl->h_meta[c->pend_slot[i]] : c->pend_host[i];
     int first = MNW_OK;
@@ -557,7 +712,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
             d.mode = mnw::kModeExplicit;
             if (j.kind == MNW_FLOAT_GROUP) d.dxq = quant_dx(j.low, j.high, j.pixels);   // group.go:305-306
             d.tile0 = tiles;
-            tiles += (j.n + mnw::kTile - 1) / mnw::kTile;
+            tiles += (j.n + mnw::kTileD - 1) / mnw::kTileD;
         }
     }
     cls_begin[3] = nslot;
@@ -566,7 +721,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     for (int cls = 0; cls < 3; ++cls) {
         const int j0 = cls_begin[cls], j1 = cls_begin[cls + 1];
         if (j1 == j0) continue;
-        int64_t tiles = sl->h_jobs[j1 - 1].tile0 + (sl->h_jobs[j1 - 1].n + mnw::kTile - 1) / mnw::kTile;
+        int64_t tiles = sl->h_jobs[j1 - 1].tile0 + (sl->h_jobs[j1 - 1].n + mnw::kTileD - 1) / mnw::kTileD;
         const int grid = grid_for(c, tiles);
         if (cls < 2) { ScopedTimer t(c, s, MNW_K_UNPACK_F32); mnw::launch_unpack_f32(s, grid, cls == 0, sl->d_jobs + j0, j1 - j0, tiles); }
         else { ScopedTimer t(c, s, MNW_K_UNPACK_I64); mnw::launch_unpack_i64(s, grid, sl->d_jobs + j0, j1 - j0, tiles); }
@@ -580,7 +735,7 @@ int mnw_pack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint64_t* x, int64_t
     if (!c || n < 0 || bits < 0) return fail(c, MNW_E_ARG, "pack: bad arguments");
     if (bits > 64) return fail(c, MNW_E_ARG, "Cannot pack more than 64 bits per element into a bit.Array");  // bit.go:85-87
     if (n == 0 || bits == 0) return MNW_OK;
-    if (!x || !out || ((uintptr_t)out & 7)) return fail(c, MNW_E_ARG, "pack: null or misaligned pointer");
+    if (!x || !out || ((uintptr_t)out & 15)) return fail(c, MNW_E_ARG, "pack: null or misaligned pointer");
     if (cap < mnw::array_bytes(bits, n)) return fail(c, MNW_E_BUFLEN, "pack: output shorter than ArrayBytes(bits, n)");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;

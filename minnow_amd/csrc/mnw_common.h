@@ -13,8 +13,9 @@ namespace mnw {
 // multiple of 64 elements so every tile's packed output starts on a 64-bit word of the block's
 // stream (64 elements at b bits = b whole words).
 constexpr int kThreads = 256;
-constexpr int kTile = 2048;               // elements per tile (8 per thread)
-constexpr int kStatSlots = 64;            // per-job stats records, one 64-B line each
+constexpr int kTile = 8192;               // encode: elements per tile (32 per thread: one packed group each)
+constexpr int kTileD = 2048;              // decode: elements per tile
+constexpr int kStatSlots = 16;            // per-job stats records, one 64-B line each
 constexpr int kStatWords = 8;             // uint64 per record
 
 // device-side job record (host fills it from mnw_enc_job / mnw_dec_job)
@@ -28,9 +29,10 @@ struct DevJob {
     int64_t min;         // decode / explicit pack: intGroup.mins[b]
     uint64_t seed;       // decode dither key
     uint64_t block;      // decode dither key
+    double rdx;          // 1.0 / double(dxq): the pack pass divides by multiplying in float64
     float low, high;
     float dxq;           // (high-low)/float32(pixels), IEEE float32, computed on the host
-    float hf;            // smallest float32 >= pixels/2 (splits the ring for the periodic stats)
+    float xh;            // least float32 x with q(x) >= pixels/2 (splits the ring for the periodic stats)
     int32_t kind;        // MNW_INT_GROUP / MNW_FLOAT_GROUP
     int32_t periodic;
     int32_t bits;        // decode / explicit pack

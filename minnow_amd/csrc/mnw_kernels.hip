@@ -23,6 +23,25 @@ namespace mnw {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+// Block pointers come out of the job records, so the compiler only knows them as generic (flat)
+// addresses; casting to the global address space turns flat_load/flat_store into global_load/
+// global_store (no LDS-aperture check, not counted in lgkmcnt).
+#define MNW_GLOBAL __attribute__((address_space(1)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+
+template <typename V, typename T>
+__device__ __forceinline__ V ldg(const T* p) { return *(const MNW_GLOBAL V*)(p); }
+template <typename V, typename T>
+__device__ __forceinline__ void stg(T* p, V v) { *(MNW_GLOBAL V*)(p) = v; }
+
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() would also drain
+// vmcnt, i.e. the prefetched global loads of the next tile that are meant to stay in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
@@ -64,6 +83,7 @@ __device__ __forceinline__ int find_job(const DevJob* jobs, int njobs, int64_t t
 }
 
 __device__ __forceinline__ int64_t tiles_of(int64_t n) { return (n + kTile - 1) / kTile; }
+__device__ __forceinline__ int64_t tiles_of_d(int64_t n) { return (n + kTileD - 1) / kTileD; }
 
 // go/group.go:318-319: float32 subtract, IEEE float32 divide, then floor.  floor() of the float32
 // quotient is exact in float32, and float64() of it is the same number, so the float64 detour of
@@ -73,65 +93,240 @@ __device__ __forceinline__ float quant_floor(float x, float low, float dx) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// reduce pass, float32 blocks: statistics of floor((x-low)/dx) kept as float32 (integers, exact).
-//   stat[0] = bias(max)   stat[1] = ~bias(min)   stat[2] = bias(max of values <  pixels/2)
-//   stat[3] = ~bias(min of values >= pixels/2)   stat[4] = 1 if NaN or |v| >= 2^63 seen
-// all combined with atomic unsigned max, so zero-filled memory is the identity.
+// reduce pass, float32 blocks.
+// q(x) = floor(fl(fl(x-low)/dx)) is monotone non-decreasing in x for dx > 0 (every step -- rounded
+// subtract, rounded divide by a positive number, floor -- is monotone), so the extreme values of q
+// over a block are q of the extreme values of x.  The pass therefore reduces the raw floats (no
+// division per element) and the pack pass quantizes just the four survivors:
+//   stat[0] = key(max x)   stat[1] = ~key(min x)
+//   stat[2] = key(max of x <  xh)   stat[3] = ~key(min of x >= xh)     xh = least float with q >= pixels/2
+//   stat[4] = 1 if a NaN or an infinity was seen
+// key() is the order-preserving map float32 -> uint32; everything is combined with atomic unsigned
+// max, so zero-filled memory is the identity (key 0 is a NaN pattern, never a real value).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float funkey(uint32_t k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
 struct FStat {
     float mn, mx, mxlo, mnhi;
     bool bad;
 };
 
-__device__ __forceinline__ void fstat_add(FStat& s, float v, float hf) {
-    s.bad |= !(fabsf(v) < 9223372036854775808.0f);   // NaN, Inf, |v| >= 2^63
-    s.mn = fminf(s.mn, v);
-    s.mx = fmaxf(s.mx, v);
-    bool lo = v < hf;
-    s.mxlo = fmaxf(s.mxlo, lo ? v : -INFINITY);
-    s.mnhi = fminf(s.mnhi, lo ? INFINITY : v);
+__device__ __forceinline__ void fstat_add(FStat& s, float x, float xh) {
+    s.bad |= !(fabsf(x) < INFINITY);                 // NaN, +-Inf
+    s.mn = fminf(s.mn, x);
+    s.mx = fmaxf(s.mx, x);
+    const bool lo = x < xh;
+    s.mxlo = fmaxf(s.mxlo, lo ? x : -INFINITY);
+    s.mnhi = fminf(s.mnhi, lo ? INFINITY : x);
 }
 
-__global__ __launch_bounds__(kThreads) void k_reduce_f32(const DevJob* __restrict__ jobs, int njobs,
-                                                         int64_t total_tiles,
-                                                         uint64_t* __restrict__ stats) {
-    __shared__ float red[4][kThreads / 64];
-    __shared__ int redbad[kThreads / 64];
-    const int tid = threadIdx.x;
-    int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
-    const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
-    if (t0 >= t1) return;
-    int j = find_job(jobs, njobs, t0);
+// ------------------------------------------------------------------------------------------------
+// block descriptor: what intGroup.writeData derives from the whole block (group.go:243-254)
+// ------------------------------------------------------------------------------------------------
+struct Desc {
+    int64_t imin;      // intGroup min (after periodic re-basing)
+    int64_t pmin;      // periodicMin result (float groups)
+    int64_t nbytes;
+    int bits;
+    int status;        // MNW_OK(0), -5 capacity, -6 domain, kNeedsExact
+};
 
+// The job's statistics = unsigned max over its stat lines; lane l reads line l % kStatSlots.
+// ATOMIC: agent-scope (sc1) loads, for words that other workgroups of the same launch have just
+// updated with agent-scope atomics; otherwise plain loads (after a kernel boundary).
+template <bool ATOMIC>
+__device__ __forceinline__ void load_stats(const uint64_t* __restrict__ stats, int j, uint64_t out[5]) {
+    const int l = lane_id();
+    const uint64_t* rec = stats + ((int64_t)j * kStatSlots + (l % kStatSlots)) * kStatWords;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        uint64_t v;
+        if (ATOMIC) v = __hip_atomic_load(rec + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else v = rec[k];
+        out[k] = wave_max_u64(v);
+    }
+}
+
+__device__ __forceinline__ bool quant_i64(float x, float low, float dx, int64_t* q) {
+    const float v = quant_floor(x, low, dx);
+    if (!(fabsf(v) < 9223372036854775808.0f)) return false;     // int64(NaN/huge) is platform defined in Go
+    *q = (int64_t)v;
+    return true;
+}
+
+// float blocks.  For q in [0,pixels) periodicMin (group.go:384-409) is order independent: it is the
+// start of the smallest ring arc covering every q if that arc is <= pixels/2 wide, else 0
+// (DESIGN.md "periodicMin as reductions"; tests/test_oracle_golden.py::test_periodic_reduction_identity).
+// Anything else (q out of range, NaN, huge) is order dependent -> exact sequential path.
+__device__ __forceinline__ Desc make_desc_f32(const DevJob& jb, const uint64_t st[5]) {
+    Desc d = {0, 0, 0, 0, 0};
+    if (st[4] != 0) { d.status = (int)kNeedsExact; return d; }
+    const bool has_lo = st[2] != 0, has_hi = st[3] != 0;
+    int64_t mx0, mn0, mxlo = 0, mnhi = 0;
+    bool ok = quant_i64(funkey((uint32_t)st[0]), jb.low, jb.dxq, &mx0);
+    ok &= quant_i64(funkey(~(uint32_t)st[1]), jb.low, jb.dxq, &mn0);
+    if (has_lo) ok &= quant_i64(funkey((uint32_t)st[2]), jb.low, jb.dxq, &mxlo);
+    if (has_hi) ok &= quant_i64(funkey(~(uint32_t)st[3]), jb.low, jb.dxq, &mnhi);
+    if (!ok) { d.status = (int)kNeedsExact; return d; }
+    uint64_t maxdelta;
+    if (jb.periodic == 1) {
+        // 32-bit pack path below needs q and q+pixels to fit 32 bits
+        if (mn0 < 0 || mx0 >= jb.pixels || jb.pixels > 0x7fffffffll) { d.status = (int)kNeedsExact; return d; }
+        const int64_t h = jb.pixels / 2;
+        if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+        else if (has_lo && has_hi && (mxlo + jb.pixels) - mnhi + 1 <= h) {
+            d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jb.pixels - mnhi);
+        } else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+    } else {
+        if (mn0 < -0x80000000ll || mx0 > 0x7fffffffll) { d.status = (int)kNeedsExact; return d; }
+        d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0);
+    }
+    d.bits = precision_needed(maxdelta);
+    d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jb.n);
+    if (d.nbytes > jb.cap) d.status = -5;
+    return d;
+}
+
+// A float block's descriptor fits one naturally aligned 8-byte word, written by ONE store and read
+// by ONE load, so it needs no ordering against anything else (it is its own flag):
+//   bit 63 ready | bits 62..55 status code | bit 54 pmin == imin (else pmin == 0) | bits 53..47 width
+//   | bits 31..0 imin (int32: q in [0,pixels) or int32 range on this path)
+constexpr uint64_t kGranReady = 1ull << 63;
+__device__ __forceinline__ uint64_t gran_encode(const Desc& d) {
+    const uint32_t code = d.status == 0 ? 0u : d.status == (int)kNeedsExact ? 1u : d.status == -5 ? 2u : 3u;
+    return kGranReady | ((uint64_t)code << 55) | ((uint64_t)(d.pmin == d.imin) << 54) |
+           ((uint64_t)(uint32_t)d.bits << 47) | (uint64_t)(uint32_t)(int32_t)d.imin;
+}
+__device__ __forceinline__ Desc gran_decode(uint64_t g, int64_t n) {
+    Desc d;
+    const uint32_t code = (uint32_t)(g >> 55) & 0xff;
+    d.status = code == 0 ? 0 : code == 1 ? (int)kNeedsExact : code == 2 ? -5 : -6;
+    d.bits = (int)((g >> 47) & 0x7f);
+    d.imin = (int64_t)(int32_t)(uint32_t)g;
+    d.pmin = ((g >> 54) & 1) ? d.imin : 0;
+    d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, n);
+    return d;
+}
+
+// Per-job synchronisation record (one 64-byte line): tiles whose statistics have been folded in, and
+// the descriptor word published by the workgroup whose arrival completed the block.
+struct JobSync {
+    uint32_t count;
+    uint32_t pad0;
+    uint64_t granule;
+    uint64_t pad1[6];
+};
+
+constexpr int kChunkF = 4 * 4 * kThreads;        // reduce pass: 4 x 16-byte loads per thread in flight
+
+// Arrivals whose statistics atomics have been issued but not yet counted in.  Counting in needs the
+// atomics drained first (s_waitcnt vmcnt(0) in the wave that issued them: wave 0); doing that right
+// after the reduce would expose a full memory round trip per stage, so in the fused launch the count
+// is deferred to a point of the following pack phase where wave 0 has just drained its loads anyway.
+constexpr int kMaxPend = 4;
+struct Pending {
+    int cnt;
+    int j[kMaxPend];
+    uint32_t n[kMaxPend];
+};
+
+// wave 0 only.  The block is complete with this arrival: derive its descriptor once, publish it as
+// one 8-byte word and write the block's metadata.  Every other producer drained its statistics
+// atomics before counting in, so agent-scope loads see all of them.
+__device__ __forceinline__ void finalize_job_f32(const DevJob* __restrict__ jobs, int j, const uint64_t* __restrict__ stats,
+                                                 JobSync* __restrict__ sync, Meta* __restrict__ meta) {
+    const DevJob jb = jobs[j];
+    uint64_t st[5];
+    load_stats<true>(stats, j, st);
+    const Desc d = make_desc_f32(jb, st);
+    if (lane_id() == 0) {
+        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+        meta[j] = m;
+        __hip_atomic_store(&sync[j].granule, gran_encode(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// wave 0 only: count the pending arrivals in (returning adds; `ret` is meaningful in lane 0)
+__device__ __forceinline__ void pend_issue(const Pending* pend, JobSync* __restrict__ sync, uint32_t (&ret)[kMaxPend]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int cnt = pend->cnt;
+#pragma unroll
+    for (int k = 0; k < kMaxPend; ++k) {
+        ret[k] = 0;
+        if (k < cnt && lane_id() == 0)
+            ret[k] = __hip_atomic_fetch_add(&sync[pend->j[k]].count, pend->n[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// wave 0 only: finalize the jobs this workgroup's arrival completed, then clear the list
+__device__ __forceinline__ void pend_finish(Pending* pend, const DevJob* __restrict__ jobs, const uint64_t* __restrict__ stats,
+                                            JobSync* __restrict__ sync, Meta* __restrict__ meta, const uint32_t (&ret)[kMaxPend]) {
+    const int cnt = pend->cnt;
+#pragma unroll
+    for (int k = 0; k < kMaxPend; ++k) {
+        if (k < cnt) {
+            const int j = pend->j[k];
+            const uint32_t before = __builtin_amdgcn_readfirstlane(ret[k]);
+            if (before + pend->n[k] == (uint32_t)tiles_of(jobs[j].n)) finalize_job_f32(jobs, j, stats, sync, meta);
+        }
+    }
+    if (lane_id() == 0) pend->cnt = 0;
+}
+
+// Reduce the tiles [t0, t1) of a launch-wide tile numbering (jobs [j0, j1) cover them).  Each
+// workgroup folds its share of a block into the block's stat lines with one 5-lane atomic instruction
+// and then counts its tiles in; the workgroup whose count completes the block derives the block's
+// descriptor (min, width, ...) once, publishes it as one 8-byte word and writes the block's metadata.
+// All cross-workgroup traffic goes through agent-scope atomics / sc1 accesses on words nothing else
+// touches, so no cache can hand out a stale copy and no fence (L2 write-back) is needed.
+__device__ __forceinline__ void reduce_range_f32(const DevJob* __restrict__ jobs, int j0, int j1, int64_t t0, int64_t t1,
+                                                 uint64_t* __restrict__ stats, JobSync* __restrict__ sync,
+                                                 Meta* __restrict__ meta, int slot,
+                                                 float (*red)[kThreads / 64], int* redbad, Pending* pend, bool defer) {
+    const int tid = threadIdx.x;
+    if (t0 >= t1) return;
+    int j = find_job(jobs + j0, j1 - j0, t0) + j0;
     while (t0 < t1) {
         const DevJob jb = jobs[j];
         const int64_t jend = jb.tile0 + tiles_of(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
         const float* __restrict__ x = (const float*)jb.src;
-        const float low = jb.low, dx = jb.dxq, hf = jb.hf;
+        const float xh = jb.xh;
         FStat s = {INFINITY, -INFINITY, -INFINITY, INFINITY, false};
 
-        for (int64_t t = t0; t < tend; ++t) {
-            const int64_t base = (t - jb.tile0) * kTile;
-            if (base + kTile <= jb.n) {
-                float4 v[kTile / (4 * kThreads)];
+        // this workgroup's element range of the block; tile boundaries do not matter to a reduction
+        int64_t c = (t0 - jb.tile0) * kTile;
+        int64_t e1 = (tend - jb.tile0) * kTile;
+        if (e1 > jb.n) e1 = jb.n;
+        // No software double buffering: a rotating register pair makes hipcc wait for the prefetch at
+        // the loop back-edge.  Bytes in flight come from occupancy and 8 independent 16-byte loads.
+        for (; c + 2 * kChunkF <= e1; c += 2 * kChunkF) {
+            f32x4 va[8];
 #pragma unroll
-                for (int k = 0; k < kTile / (4 * kThreads); ++k)
-                    v[k] = *reinterpret_cast<const float4*>(x + base + 4 * (k * kThreads + tid));
+            for (int k = 0; k < 8; ++k) va[k] = ldg<f32x4>(x + c + 4 * (k * kThreads + tid));
 #pragma unroll
-                for (int k = 0; k < kTile / (4 * kThreads); ++k) {
-                    fstat_add(s, quant_floor(v[k].x, low, dx), hf);
-                    fstat_add(s, quant_floor(v[k].y, low, dx), hf);
-                    fstat_add(s, quant_floor(v[k].z, low, dx), hf);
-                    fstat_add(s, quant_floor(v[k].w, low, dx), hf);
-                }
-            } else {
-                for (int64_t i = base + tid; i < jb.n; i += kThreads)
-                    fstat_add(s, quant_floor(x[i], low, dx), hf);
+            for (int k = 0; k < 8; ++k) {
+                fstat_add(s, va[k].x, xh); fstat_add(s, va[k].y, xh);
+                fstat_add(s, va[k].z, xh); fstat_add(s, va[k].w, xh);
             }
         }
+        for (; c + kChunkF <= e1; c += kChunkF) {
+            f32x4 va[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) va[k] = ldg<f32x4>(x + c + 4 * (k * kThreads + tid));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                fstat_add(s, va[k].x, xh); fstat_add(s, va[k].y, xh);
+                fstat_add(s, va[k].z, xh); fstat_add(s, va[k].w, xh);
+            }
+        }
+        for (int64_t i = c + tid; i < e1; i += kThreads) fstat_add(s, ldg<float>(x + i), xh);
 
-        // workgroup reduction, then one 5-lane atomic instruction into this workgroup's stat line
         float mn = wave_min(s.mn), mx = wave_max(s.mx), mxlo = wave_max(s.mxlo), mnhi = wave_min(s.mnhi);
         int bad = __any(s.bad);
         __syncthreads();
@@ -141,34 +336,66 @@ __global__ __launch_bounds__(kThreads) void k_reduce_f32(const DevJob* __restric
             redbad[wave_id()] = bad;
         }
         __syncthreads();
-        if (tid < 5) {
-            float a = red[0][0], b = red[1][0], c = red[2][0], d = red[3][0];
-            int bd = redbad[0];
+        if (tid < 64) {                               // wave 0 publishes
+            if (tid < 5) {
+                float a = red[0][0], b = red[1][0], c2 = red[2][0], d = red[3][0];
+                int bd = redbad[0];
 #pragma unroll
-            for (int w = 1; w < kThreads / 64; ++w) {
-                a = fminf(a, red[0][w]); b = fmaxf(b, red[1][w]);
-                c = fmaxf(c, red[2][w]); d = fminf(d, red[3][w]);
-                bd |= redbad[w];
+                for (int w = 1; w < kThreads / 64; ++w) {
+                    a = fminf(a, red[0][w]); b = fmaxf(b, red[1][w]);
+                    c2 = fmaxf(c2, red[2][w]); d = fminf(d, red[3][w]);
+                    bd |= redbad[w];
+                }
+                // -inf / +inf mean "no element in that half"; they map to the identity (0)
+                uint64_t val;
+                if (tid == 0) val = bd ? 0 : fkey(b);
+                else if (tid == 1) val = bd ? 0 : (uint32_t)~fkey(a);
+                else if (tid == 2) val = (bd || c2 == -INFINITY) ? 0 : fkey(c2);
+                else if (tid == 3) val = (bd || d == INFINITY) ? 0 : (uint32_t)~fkey(d);
+                else val = bd ? 1 : 0;
+                uint64_t* rec = stats + ((int64_t)j * kStatSlots + slot) * kStatWords;
+                if (val != 0) atomicMax((unsigned long long*)(rec + tid), (unsigned long long)val);
             }
-            // -inf / +inf mean "no element in that half"; they map to the identity (0)
-            uint64_t val;
-            if (tid == 0) val = bd ? 0 : bias((int64_t)b);
-            else if (tid == 1) val = bd ? 0 : ~bias((int64_t)a);
-            else if (tid == 2) val = (bd || c == -INFINITY) ? 0 : bias((int64_t)c);
-            else if (tid == 3) val = (bd || d == INFINITY) ? 0 : ~bias((int64_t)d);
-            else val = bd ? 1 : 0;
-            uint64_t* rec = stats + ((int64_t)j * kStatSlots + (blockIdx.x % kStatSlots)) * kStatWords;
-            if (val != 0) atomicMax((unsigned long long*)(rec + tid), (unsigned long long)val);
+            int npend = 0;
+            if (tid == 0) {
+                const int k = pend->cnt;
+                pend->j[k] = j;
+                pend->n[k] = (uint32_t)(tend - t0);
+                pend->cnt = npend = k + 1;
+            }
+            npend = __builtin_amdgcn_readfirstlane(npend);
+            // count in now (full round trips) unless the caller hides that in the pack phase that follows
+            if (!defer || npend == kMaxPend) {
+                uint32_t ret[kMaxPend];
+                pend_issue(pend, sync, ret);
+                pend_finish(pend, jobs, stats, sync, meta, ret);
+            }
         }
         t0 = tend;
         ++j;
     }
 }
 
+__global__ __launch_bounds__(kThreads, 8) void k_reduce_f32(const DevJob* __restrict__ jobs, int njobs,
+                                                         int64_t total_tiles,
+                                                         uint64_t* __restrict__ stats, JobSync* __restrict__ sync,
+                                                         Meta* __restrict__ meta) {
+    __shared__ float red[4][kThreads / 64];
+    __shared__ int redbad[kThreads / 64];
+    __shared__ Pending pend;
+    if (threadIdx.x == 0) pend.cnt = 0;
+    __syncthreads();
+    const int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
+    reduce_range_f32(jobs, 0, njobs, t0, t1, stats, sync, meta, blockIdx.x % kStatSlots, red, redbad, &pend, false);
+}
+
 // ------------------------------------------------------------------------------------------------
 // reduce pass, int64 blocks (go/group.go:350-357 int64Min, bit.go:151-159 max of x-min)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_reduce_i64(const DevJob* __restrict__ jobs, int njobs,
+constexpr int kChunkI = 4 * 2 * kThreads;        // 4 x 16-byte loads per thread in flight
+
+__global__ __launch_bounds__(kThreads, 8) void k_reduce_i64(const DevJob* __restrict__ jobs, int njobs,
                                                          int64_t total_tiles,
                                                          uint64_t* __restrict__ stats) {
     __shared__ int64_t red[2][kThreads / 64];
@@ -185,24 +412,22 @@ __global__ __launch_bounds__(kThreads) void k_reduce_i64(const DevJob* __restric
         const int64_t* __restrict__ x = (const int64_t*)jb.src;
         int64_t mn = INT64_MAX, mx = INT64_MIN;
 
-        for (int64_t t = t0; t < tend; ++t) {
-            const int64_t base = (t - jb.tile0) * kTile;
-            if (base + kTile <= jb.n) {
-                longlong2 v[kTile / (2 * kThreads)];
+        int64_t c = (t0 - jb.tile0) * kTile;
+        int64_t e1 = (tend - jb.tile0) * kTile;
+        if (e1 > jb.n) e1 = jb.n;
+        for (; c + kChunkI <= e1; c += kChunkI) {
+            i64x2 va[4];
 #pragma unroll
-                for (int k = 0; k < kTile / (2 * kThreads); ++k)
-                    v[k] = *reinterpret_cast<const longlong2*>(x + base + 2 * (k * kThreads + tid));
+            for (int k = 0; k < 4; ++k) va[k] = ldg<i64x2>(x + c + 2 * (k * kThreads + tid));
 #pragma unroll
-                for (int k = 0; k < kTile / (2 * kThreads); ++k) {
-                    mn = v[k].x < mn ? v[k].x : mn; mx = v[k].x > mx ? v[k].x : mx;
-                    mn = v[k].y < mn ? v[k].y : mn; mx = v[k].y > mx ? v[k].y : mx;
-                }
-            } else {
-                for (int64_t i = base + tid; i < jb.n; i += kThreads) {
-                    int64_t v = x[i];
-                    mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-                }
+            for (int k = 0; k < 4; ++k) {
+                mn = va[k].x < mn ? va[k].x : mn; mx = va[k].x > mx ? va[k].x : mx;
+                mn = va[k].y < mn ? va[k].y : mn; mx = va[k].y > mx ? va[k].y : mx;
             }
+        }
+        for (int64_t i = c + tid; i < e1; i += kThreads) {
+            const int64_t v = ldg<int64_t>(x + i);
+            mn = v < mn ? v : mn; mx = v > mx ? v : mx;
         }
         mn = wave_min_i64(mn);
         mx = wave_max_i64(mx);
@@ -225,53 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_i64(const DevJob* __restric
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// block descriptor: what intGroup.writeData derives from the whole block (group.go:243-254)
-// ------------------------------------------------------------------------------------------------
-struct Desc {
-    int64_t imin;      // intGroup min (after periodic re-basing)
-    int64_t pmin;      // periodicMin result (float groups)
-    int64_t nbytes;
-    int bits;
-    int status;        // MNW_OK(0), -5 capacity, -6 domain, kNeedsExact
-};
-
-// Every lane reads one stat line; wave-wide unsigned max gives the job's statistics.
-__device__ __forceinline__ void load_stats(const uint64_t* __restrict__ stats, int j, uint64_t out[5]) {
-    const uint64_t* rec = stats + ((int64_t)j * kStatSlots + lane_id()) * kStatWords;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) out[k] = wave_max_u64(rec[k]);
-}
-
-// float blocks.  For q in [0,pixels) periodicMin (group.go:384-409) is order independent: it is the
-// start of the smallest ring arc covering every q if that arc is <= pixels/2 wide, else 0
-// (DESIGN.md "periodicMin as reductions"; tests/test_oracle_golden.py::test_periodic_reduction_identity).
-// Anything else (q out of range, NaN, huge) is order dependent -> exact sequential path.
-__device__ __forceinline__ Desc make_desc_f32(const DevJob& jb, const uint64_t st[5]) {
-    Desc d = {0, 0, 0, 0, 0};
-    if (st[4] != 0) { d.status = (int)kNeedsExact; return d; }
-    const int64_t mx0 = unbias(st[0]), mn0 = unbias(~st[1]);
-    const bool has_lo = st[2] != 0, has_hi = st[3] != 0;
-    const int64_t mxlo = unbias(st[2]), mnhi = unbias(~st[3]);
-    uint64_t maxdelta;
-    if (jb.periodic == 1) {
-        // 32-bit pack path below needs q and q+pixels to fit 32 bits
-        if (mn0 < 0 || mx0 >= jb.pixels || jb.pixels > 0x7fffffffll) { d.status = (int)kNeedsExact; return d; }
-        const int64_t h = jb.pixels / 2;
-        if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-        else if (has_lo && has_hi && (mxlo + jb.pixels) - mnhi + 1 <= h) {
-            d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jb.pixels - mnhi);
-        } else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-    } else {
-        if (mn0 < -0x80000000ll || mx0 > 0x7fffffffll) { d.status = (int)kNeedsExact; return d; }
-        d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0);
-    }
-    d.bits = precision_needed(maxdelta);
-    d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jb.n);
-    if (d.nbytes > jb.cap) d.status = -5;
-    return d;
-}
-
+// int64 blocks
 __device__ __forceinline__ Desc make_desc_i64(const DevJob& jb, const uint64_t st[5]) {
     Desc d = {0, 0, 0, 0, 0};
     if (jb.mode == kModeExplicit) { d.imin = jb.min; d.bits = jb.bits; }
@@ -287,203 +466,440 @@ __device__ __forceinline__ Desc make_desc_i64(const DevJob& jb, const uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------------
-// word assembly: output word w of a tile from the staged re-based values (LDS), b bits each.
-// Word w covers stream bits [64w, 64w+64): it starts inside element e0 = 64w/b at bit o.
+// pack core.  32 consecutive elements at b bits are exactly b 32-bit words of the stream, so one
+// lane packs 32 consecutive re-based values into b words with no cross-lane traffic, and because b
+// is the same for the whole block, every lane is at the same bit position at the same time: the
+// flush test is wave-uniform (scalar branch) and an element costs one v_lshl_or_b32.
+//
+// Tile = 8192 elements = 256 lanes x 32.  Data path of one tile:
+//   coalesced 16-B global loads -> quantize/re-base -> LDS stage (natural order, 32-element groups
+//   at a 36-dword stride so the transposed reads below are bank-conflict free)
+//   -> each lane reads ITS 32 values (8 x ds_read_b128) -> packs -> writes its b words to LDS in
+//   stream order -> coalesced 16-B LDS reads -> coalesced 16-B global stores.
 // ------------------------------------------------------------------------------------------------
-template <typename T>   // T = uint32_t (b <= 32) or uint64_t (b <= 64); values already < 2^b
-__device__ __forceinline__ uint64_t assemble_word(const T* __restrict__ d, uint32_t w, uint32_t b,
-                                                  uint32_t magic) {
-    const uint32_t bitpos = w * 64u;
-    // floor(bitpos / b): magic = ceil(2^32/b) is exact for bitpos*b < 2^32; b == 1 has no 32-bit magic
-    uint32_t e = b == 1 ? bitpos : __umulhi(bitpos, magic);
-    const uint32_t o = bitpos - e * b;
-    uint64_t acc = (uint64_t)d[e] >> o;
-    uint32_t pos = b - o;
-    ++e;
-    while (pos < 64u) {
-        acc |= (uint64_t)d[e] << pos;
+constexpr int kGroup = 32;                         // elements packed by one lane
+constexpr int kStride32 = kGroup + 4;              // dwords between groups of 32-bit values
+constexpr int kStride64 = 2 * kGroup + 4;          // dwords between groups of 64-bit values
+constexpr int kLds32 = kThreads * kStride32 * 4;   // 36,864 B
+constexpr int kLds64 = kThreads * kStride64 * 4;   // 69,632 B
+static_assert(kTile == kThreads * kGroup, "one lane packs one group of the tile");
+
+// position of element e of the tile in the padded 32-bit stage (dword index)
+__device__ __forceinline__ int stage32_idx(int e) { return e + 4 * (e >> 5); }
+__device__ __forceinline__ int stage64_idx(int e) { return 2 * e + 4 * (e >> 5); }   // dword index
+
+// Pack this lane's 32 values (already < 2^b) and write its b words to out[0..b).
+// b must be wave-uniform and live in an SGPR (readfirstlane) so the branches are scalar.
+__device__ __forceinline__ void pack_group32(const uint32_t (&v)[kGroup], uint32_t b, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    uint32_t pos = 0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+        acc |= v[i] << pos;                        // bits above 32 fall off; picked up below
         pos += b;
-        ++e;
-    }
-    return acc;
-}
-
-// store the words of one tile: full 64-bit words coalesced, the last partial word of a block
-// byte-wise (ArrayBytes is a byte count, bit.go:23-25; pad bits are zero, bit.go:94)
-template <typename T>
-__device__ __forceinline__ void store_tile_words(const T* __restrict__ d, uint8_t* __restrict__ out,
-                                                 int64_t tile_byte0, int64_t tile_bytes, uint32_t b,
-                                                 uint32_t magic) {
-    const uint32_t full = (uint32_t)(tile_bytes >> 3);
-    uint64_t* o64 = reinterpret_cast<uint64_t*>(out + tile_byte0);
-    for (uint32_t w = threadIdx.x; w < full; w += kThreads) o64[w] = assemble_word<T>(d, w, b, magic);
-    const uint32_t rem = (uint32_t)(tile_bytes & 7);
-    if (rem != 0 && threadIdx.x == 0) {
-        uint64_t v = assemble_word<T>(d, full, b, magic);
-        uint8_t* p = out + tile_byte0 + (int64_t)full * 8;
-        for (uint32_t k = 0; k < rem; ++k) p[k] = (uint8_t)(v >> (8 * k));
+        if (pos >= 32) {                           // wave-uniform
+            *out++ = acc;
+            pos -= 32;
+            acc = pos ? v[i] >> (b - pos) : 0;     // the part of v[i] that did not fit
+        }
     }
 }
 
-constexpr int kLdsBytes = 2 * kTile * 4 + 64;      // two 32-bit staging buffers (or one 64-bit) + pad
+// 33..64-bit values: each is the field pair (low 32 bits, high b-32 bits) of the same LSB-first stream
+__device__ __forceinline__ void pack_group64(const uint64_t (&v)[kGroup], uint32_t b, uint32_t* __restrict__ out) {
+    uint32_t acc = 0;
+    uint32_t pos = 0;
+    const uint32_t bh = b - 32;                    // 1..32
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+        const uint32_t lo = (uint32_t)v[i], hi = (uint32_t)(v[i] >> 32);
+        // low field, width 32: always completes a word
+        acc |= lo << pos;
+        *out++ = acc;
+        acc = pos ? lo >> (32 - pos) : 0;
+        // high field, width bh
+        acc |= hi << pos;
+        pos += bh;
+        if (pos >= 32) {
+            *out++ = acc;
+            pos -= 32;
+            acc = pos ? hi >> (bh - pos) : 0;
+        }
+    }
+}
+
+// coalesced write-out of one tile's packed words from LDS: 16-byte chunks, then the ragged tail of
+// the block's last tile byte-wise (ArrayBytes is a byte count, bit.go:23-25; pad bits are zero)
+__device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out, uint8_t* __restrict__ dst,
+                                           int64_t tile_byte0, int64_t tile_bytes) {
+    const int full = (int)(tile_bytes >> 4);
+    for (int c = threadIdx.x; c < full; c += kThreads)
+        stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(lds_out + 4 * c));
+    const int rem = (int)(tile_bytes & 15);
+    if ((int)threadIdx.x < rem) {
+        const int k = threadIdx.x;
+        const uint32_t w = lds_out[4 * full + (k >> 2)];
+        stg<uint8_t>(dst + tile_byte0 + 16 * (int64_t)full + k, (uint8_t)(w >> (8 * (k & 3))));
+    }
+}
+
+// go/group.go:318-319 with the division done as a float64 multiply by 1/dx.  For float32 t, dx the
+// value RN32(RN64(double(t) * RN64(1/double(dx)))) equals the correctly rounded float32 quotient:
+// the double product is within 2^-52 (relative) of t/dx, and a quotient of two 24-bit significands is
+// never closer than 2^-49 (relative) to a float32 rounding boundary (DESIGN.md "Quantize").  The
+// argument needs a normal float32 result; tiny quotients take the IEEE division.
+__device__ __forceinline__ float quant_floor_fast(float x, float low, float dx, double rdx) {
+    const float t = __fsub_rn(x, low);
+    float r = (float)__dmul_rn((double)t, rdx);
+    if (__builtin_expect(fabsf(r) < 1.17549435e-38f, 0)) r = __fdiv_rn(t, dx);
+    return floorf(r);
+}
+
+// the float64-multiply quotient alone (no guard); see quant_floor_fast
+__device__ __forceinline__ float quant_mul(float x, float low, double rdx) {
+    return (float)__dmul_rn((double)__fsub_rn(x, low), rdx);
+}
 
 // ------------------------------------------------------------------------------------------------
 // pack pass, float32 blocks (32-bit path: q in [0,pixels), pixels < 2^31, or int32-range q when
-// not periodic).  One barrier per tile: the 32-bit staging buffer is double buffered.
+// not periodic)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_pack_f32(const DevJob* __restrict__ jobs, int njobs,
-                                                       int64_t total_tiles,
-                                                       const uint64_t* __restrict__ stats,
-                                                       Meta* __restrict__ meta) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsBytes / 4];
+// Diagnostic builds only (-DMNW_STAMPS, tools/microbench): per-phase cycle sums of wave 0 of every
+// workgroup, written to a buffer no other code reads.  The shipped library has no stamps.
+#ifdef MNW_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ int g_dbg_skip = 0;
+#define MNW_STAMP_DECL unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
+#define MNW_STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define MNW_STAMP(i) { unsigned long long t2_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc[i] += t2_ - st_t; st_t = t2_; }
+#define MNW_STAMP_FLUSH if (g_stamp_buf && threadIdx.x == 0) { st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_rt0; st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0; for (int i_ = 0; i_ < 8; ++i_) g_stamp_buf[blockIdx.x * 8 + i_] += st_acc[i_]; }
+#else
+#define MNW_STAMP_DECL
+#define MNW_STAMP_START
+#define MNW_STAMP(i)
+#define MNW_STAMP_FLUSH
+#endif
+
+// Descriptor of job j for the pack phase.  After a kernel boundary it is simply there; inside the
+// fused launch one lane polls the 8-byte word (relaxed agent-scope load, bounded spin: a timeout or
+// another workgroup's timeout aborts the launch and the host reruns the batch through the two-kernel
+// path).  `pref` is a value loaded earlier (0 if none).  Returns false when aborted.
+template <bool FUSED>
+__device__ __forceinline__ bool get_granule(JobSync* __restrict__ sync, uint32_t* __restrict__ abort_flag, int j,
+                                            uint64_t pref, uint64_t* shared_slot, uint64_t* out) {
+    if (!FUSED) { *out = sync[j].granule; return true; }
+    if (threadIdx.x == 0) {
+        uint64_t g = pref;
+        uint32_t spins = 0;
+        while (!(g & kGranReady)) {
+            g = __hip_atomic_load(&sync[j].granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g & kGranReady) break;
+            __builtin_amdgcn_s_sleep(8);
+            ++spins;
+            if ((spins & 15) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { g = 0; break; }
+            if (spins > (1u << 18)) {            // ~0.3 s: something keeps the producers from running
+                __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g = 0;
+                break;
+            }
+        }
+        *shared_slot = g;
+    }
+    __syncthreads();
+    const uint64_t g = *shared_slot;
+    __syncthreads();
+    *out = g;
+    return (g & kGranReady) != 0;
+}
+
+// Pack the tiles [t0, t1) of a launch-wide tile numbering.  Returns false if the fused launch aborted.
+template <bool FUSED>
+__device__ __forceinline__ bool pack_range_f32(uint32_t* __restrict__ lds, uint64_t* shared_slot,
+                                               const DevJob* __restrict__ jobs, int j0, int j1, int64_t t0, int64_t t1,
+                                               JobSync* __restrict__ sync, uint32_t* __restrict__ abort_flag,
+                                               uint64_t pref, Pending* pend, const uint64_t* __restrict__ stats,
+                                               Meta* __restrict__ meta) {
+    constexpr int kV = kTile / (4 * kThreads);       // 16-byte loads per thread per tile (8)
     const int tid = threadIdx.x;
-    int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
-    const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
-    if (t0 >= t1) return;
-    int j = find_job(jobs, njobs, t0);
-    int buf = 0;
-    if (tid < 16) lds[2 * kTile + tid] = 0;         // pad read by the last word's look-ahead
+    // deferred arrivals of the preceding reduce phase (fused launch, wave 0): 0 = none,
+    // 1 = to be counted in at the next point where wave 0 has drained its loads, 2 = counted in,
+    // results to be looked at one tile later (they are older than that tile's loads)
+    int pstate = (FUSED && wave_id() == 0 && pend->cnt > 0) ? 1 : 0;
+    uint32_t pret[kMaxPend] = {0, 0, 0, 0};
+    if (t0 >= t1) {
+        if (FUSED && pstate == 1) { pend_issue(pend, sync, pret); pend_finish(pend, jobs, stats, sync, meta, pret); }
+        return true;
+    }
+    MNW_STAMP_DECL
+    MNW_STAMP_START
+    int j = find_job(jobs + j0, j1 - j0, t0) + j0;
 
     while (t0 < t1) {
         const DevJob jb = jobs[j];
         const int64_t jend = jb.tile0 + tiles_of(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
-        uint64_t st[5];
-        load_stats(stats, j, st);
-        const Desc d = make_desc_f32(jb, st);
-        if (t0 == jb.tile0 && tid == 0) {
-            Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
-            meta[j] = m;
+        const float* __restrict__ x = (const float*)jb.src;
+        // The range is walked backwards (the tiles this workgroup reduced last are the likeliest to
+        // still be cached).  Only the block's last tile can be ragged and it comes first, so every
+        // prefetched tile is full.  The first tile's loads are issued before the descriptor is waited
+        // for so that the latencies overlap.
+        int64_t t = tend - 1;
+        f32x4 v[kV];
+        bool cur_full = (t - jb.tile0) * kTile + kTile <= jb.n;
+        if (cur_full) {
+#pragma unroll
+            for (int k = 0; k < kV; ++k) v[k] = ldg<f32x4>(x + (t - jb.tile0) * kTile + 4 * (k * kThreads + tid));
         }
-        if (d.status == 0 && d.bits != 0) {
-            const float* __restrict__ x = (const float*)jb.src;
+        uint64_t gran;
+        if (!get_granule<FUSED>(sync, abort_flag, j, pref, shared_slot, &gran)) return false;
+        pref = 0;
+        const Desc d = gran_decode(gran, jb.n);
+        const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
+        MNW_STAMP(0)      // preamble: job record, first loads issued, descriptor
+        if (ok) {
             const float low = jb.low, dx = jb.dxq;
-            const uint32_t b = (uint32_t)d.bits;
-            const uint32_t magic = (uint32_t)((0x100000000ull + b - 1) / b);
+            const double rdx = jb.rdx;
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
             const int32_t pmin = (int32_t)d.pmin;
             const uint32_t imin = (uint32_t)(int32_t)d.imin, pix = (uint32_t)jb.pixels;
             const bool per = jb.periodic == 1;
-            // walk the range backwards: the tiles this workgroup reduced last are the likeliest to
-            // still sit in its XCD's L2
-            for (int64_t t = tend - 1; t >= t0; --t) {
+            for (; t >= t0; --t) {
                 const int64_t base = (t - jb.tile0) * kTile;
-                uint32_t* stage = lds + buf * kTile;
-                if (base + kTile <= jb.n) {
-                    float4 v[kTile / (4 * kThreads)];
+                if (cur_full) {
+                    // quantize through the float64 multiply; quotients too small for that argument
+                    // (|r| below the float32 normal range) are redone with the IEEE division, for the
+                    // whole tile at once so that the common path has no per-element branch
+                    bool tiny = false;
 #pragma unroll
-                    for (int k = 0; k < kTile / (4 * kThreads); ++k)
-                        v[k] = *reinterpret_cast<const float4*>(x + base + 4 * (k * kThreads + tid));
-#pragma unroll
-                    for (int k = 0; k < kTile / (4 * kThreads); ++k) {
-                        const float f[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                        uint4 r;
-                        uint32_t* rp = reinterpret_cast<uint32_t*>(&r);
+                    for (int k = 0; k < kV; ++k) {
+                        u32x4 r;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const int32_t q = (int32_t)quant_floor(f[c], low, dx);
+                            const float rq = quant_mul(v[k][c], low, rdx);
+                            tiny |= fabsf(rq) < 1.17549435e-38f;
+                            const int32_t q = (int32_t)floorf(rq);
                             uint32_t uq = (uint32_t)q;
                             if (per && q < pmin) uq += pix;         // bound(), group.go:374-382
-                            rp[c] = uq - imin;                      // group.go:247
+                            r[c] = uq - imin;                       // group.go:247
                         }
-                        *reinterpret_cast<uint4*>(stage + 4 * (k * kThreads + tid)) = r;
+                        *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreads + tid))) = r;
+                    }
+                    if (__builtin_expect(__any(tiny), 0)) {
+#pragma unroll 1
+                        for (int k = 0; k < kV; ++k) {
+                            u32x4 r;
+                            for (int c = 0; c < 4; ++c) {
+                                const int32_t q = (int32_t)quant_floor(v[k][c], low, dx);
+                                uint32_t uq = (uint32_t)q;
+                                if (per && q < pmin) uq += pix;
+                                r[c] = uq - imin;
+                            }
+                            *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreads + tid))) = r;
+                        }
                     }
                 } else {
                     for (int i = tid; i < kTile; i += kThreads) {
                         uint32_t r = 0;
                         if (base + i < jb.n) {
-                            const int32_t q = (int32_t)quant_floor(x[base + i], low, dx);
+                            const int32_t q = (int32_t)quant_floor(ldg<float>(x + base + i), low, dx);
                             uint32_t uq = (uint32_t)q;
                             if (per && q < pmin) uq += pix;
                             r = uq - imin;
                         }
-                        stage[i] = r;
+                        lds[stage32_idx(i)] = r;
                     }
                 }
-                __syncthreads();
-                const int64_t tile_byte0 = base / 8 * b;           // base is a multiple of 64
+                MNW_STAMP(1)  // wait for the tile's loads + quantize + stage
+                if (FUSED) {
+                    // wave 0 has just consumed every load it had in flight: anything older -- the
+                    // statistics atomics of the reduce phase -- has completed too
+                    if (pstate == 2) { pend_finish(pend, jobs, stats, sync, meta, pret); pstate = 0; }
+                    else if (pstate == 1) { pend_issue(pend, sync, pret); pstate = 2; }
+                }
+                if (t - 1 >= t0) {                   // next tile: loads stay in flight across the barriers
+#pragma unroll
+                    for (int k = 0; k < kV; ++k) v[k] = ldg<f32x4>(x + base - kTile + 4 * (k * kThreads + tid));
+                }
+                cur_full = true;
+                lds_barrier();
+                MNW_STAMP(2)  // prefetch issue + barrier
+                uint32_t g[kGroup];
+#pragma unroll
+                for (int k = 0; k < kGroup / 4; ++k) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+                    g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+                }
+                lds_barrier();                      // everyone holds its group: the stage can be overwritten
+                MNW_STAMP(3)  // transposed LDS read + barrier
+                pack_group32(g, b, lds + tid * b);
+                lds_barrier();
+                MNW_STAMP(4)  // pack + barrier
+                const int64_t tile_byte0 = base / 8 * b;
                 int64_t tile_bytes = (int64_t)kTile / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile_words<uint32_t>(stage, (uint8_t*)jb.dst, tile_byte0, tile_bytes, b, magic);
-                buf ^= 1;
+                store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                lds_barrier();                      // write-out done before the next tile is staged
+                MNW_STAMP(5)  // LDS read-out + global stores issued + barrier
             }
         }
         t0 = tend;
         ++j;
     }
+    if (FUSED) {
+        if (pstate == 1) { pend_issue(pend, sync, pret); pstate = 2; }
+        if (pstate == 2) pend_finish(pend, jobs, stats, sync, meta, pret);
+    }
+    MNW_STAMP_FLUSH
+    return true;
+}
+
+__global__ __launch_bounds__(kThreads) void k_pack_f32(const DevJob* __restrict__ jobs, int njobs,
+                                                       int64_t total_tiles, JobSync* __restrict__ sync) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds32 / 4];
+    __shared__ uint64_t shared_slot;
+    const int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
+    pack_range_f32<false>(lds, &shared_slot, jobs, 0, njobs, t0, t1, sync, nullptr, 0, nullptr, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused float32 encode: ONE persistent launch for a whole batch.  The batch is cut into groups of
+// consecutive blocks (tiles gtile[g] .. gtile[g+1] of the batch-wide numbering, jobs gjob[g] ..
+// gjob[g+1]).  Every workgroup owns the same slice of every group and runs
+//     R(0) | R(1) P(0) | R(2) P(1) | ... | P(ng-1)
+// so the reduce of group g runs ahead of the pack of group g-1: by the time a workgroup asks for a
+// block's descriptor its producers have normally finished.  There is no grid barrier, only per-block
+// arrival counters and one published word per block.  HBM reads (next group), Infinity-Cache
+// re-reads (previous group) and HBM writes overlap inside one launch; launch, ramp and the final L2
+// write-back are paid once per batch.
+// The grid must be co-resident (the host sizes it from the occupancy query); every spin is bounded.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restrict__ jobs, int njobs,
+                                                         const int64_t* __restrict__ gtile, const int* __restrict__ gjob,
+                                                         int ngroups, uint64_t* __restrict__ stats,
+                                                         JobSync* __restrict__ sync, uint32_t* __restrict__ abort_flag,
+                                                         Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds32 / 4];
+    __shared__ float red[4][kThreads / 64];
+    __shared__ int redbad[kThreads / 64];
+    __shared__ uint64_t shared_slot;
+    __shared__ Pending pend;
+    const int slot = blockIdx.x % kStatSlots;
+#ifdef MNW_STAMPS
+    const int dbg_skip = g_dbg_skip;     // diagnostic builds only: 1 = no reduce phase, 2 = no pack phase
+#else
+    constexpr int dbg_skip = 0;
+#endif
+    if (threadIdx.x == 0) pend.cnt = 0;
+    __syncthreads();
+    for (int g = 0; g <= ngroups; ++g) {
+        // the pack phase of this stage starts with the first block of this workgroup's slice of group
+        // g-1: ask for that block's descriptor now, so the answer is in a register after the reduce
+        uint64_t pref = 0;
+        int64_t pa = 0, pb = 0;
+        if (g >= 1) {
+            const int64_t a = gtile[g - 1], n = gtile[g] - a;
+            pa = a + n * blockIdx.x / gridDim.x;
+            pb = a + n * (blockIdx.x + 1) / gridDim.x;
+            if (pa < pb && threadIdx.x == 0) {
+                const int jl = find_job(jobs + gjob[g - 1], gjob[g] - gjob[g - 1], pa) + gjob[g - 1];
+                pref = __hip_atomic_load(&sync[jl].granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const bool packs = g >= 1 && pa < pb && !(dbg_skip & 2);
+        if (g < ngroups && !(dbg_skip & 1)) {
+            const int64_t a = gtile[g], n = gtile[g + 1] - a;
+            reduce_range_f32(jobs, gjob[g], gjob[g + 1], a + n * blockIdx.x / gridDim.x,
+                             a + n * (blockIdx.x + 1) / gridDim.x, stats, sync, meta, slot, red, redbad, &pend, packs);
+        }
+        if (g >= 1 && !(dbg_skip & 2)) {
+            if (!pack_range_f32<true>(lds, &shared_slot, jobs, gjob[g - 1], gjob[g], pa, pb, sync, abort_flag, pref,
+                                      &pend, stats, meta)) return;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // pack pass, int64 blocks (intGroup.writeData, and raw bit.BufferedArray in explicit mode).
-// b <= 32: 32-bit staging, double buffered; b > 32: 64-bit staging, single buffer, two barriers.
+// The width is only known on the device, so the kernel carries both the 32-bit and the 64-bit path.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict__ jobs, int njobs,
                                                        int64_t total_tiles,
                                                        const uint64_t* __restrict__ stats,
                                                        Meta* __restrict__ meta) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds64 / 4];
+    constexpr int kV = kTile / (2 * kThreads);       // 16-byte loads per thread per tile (16)
     const int tid = threadIdx.x;
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
     int j = find_job(jobs, njobs, t0);
-    int buf = 0;
-    if (tid < 16) lds[2 * kTile + tid] = 0;
 
     while (t0 < t1) {
         const DevJob jb = jobs[j];
         const int64_t jend = jb.tile0 + tiles_of(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
         uint64_t st[5] = {0, 0, 0, 0, 0};
-        if (jb.mode == kModeStats) load_stats(stats, j, st);
+        if (jb.mode == kModeStats) load_stats<false>(stats, j, st);
         const Desc d = make_desc_i64(jb, st);
         if (t0 == jb.tile0 && tid == 0) {
             Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
             meta[j] = m;
         }
-        if (d.status == 0 && d.bits != 0) {
+        const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
+        if (ok) {
             const int64_t* __restrict__ x = (const int64_t*)jb.src;
-            const uint32_t b = (uint32_t)d.bits;
-            const uint32_t magic = (uint32_t)((0x100000000ull + b - 1) / b);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
             const uint64_t imin = (uint64_t)d.imin;
             const uint64_t mask = b == 64 ? ~0ull : ((1ull << b) - 1);   // bit.go:104-107
             const bool narrow = b <= 32;
             for (int64_t t = tend - 1; t >= t0; --t) {
                 const int64_t base = (t - jb.tile0) * kTile;
-                uint32_t* stage32 = lds + buf * kTile;
-                uint64_t* stage64 = reinterpret_cast<uint64_t*>(lds);
-                if (!narrow) __syncthreads();                      // single buffer: readers done
                 if (base + kTile <= jb.n) {
-                    longlong2 v[kTile / (2 * kThreads)];
-#pragma unroll
-                    for (int k = 0; k < kTile / (2 * kThreads); ++k)
-                        v[k] = *reinterpret_cast<const longlong2*>(x + base + 2 * (k * kThreads + tid));
-#pragma unroll
-                    for (int k = 0; k < kTile / (2 * kThreads); ++k) {
-                        const uint64_t a = ((uint64_t)v[k].x - imin) & mask;
-                        const uint64_t c = ((uint64_t)v[k].y - imin) & mask;
+#pragma unroll 4
+                    for (int k = 0; k < kV; ++k) {
+                        const i64x2 v = ldg<i64x2>(x + base + 2 * (k * kThreads + tid));
+                        const uint64_t a = ((uint64_t)v.x - imin) & mask;
+                        const uint64_t c = ((uint64_t)v.y - imin) & mask;
                         const int e = 2 * (k * kThreads + tid);
-                        if (narrow) *reinterpret_cast<uint2*>(stage32 + e) = make_uint2((uint32_t)a, (uint32_t)c);
-                        else *reinterpret_cast<ulonglong2*>(stage64 + e) = make_ulonglong2(a, c);
+                        if (narrow) { u32x2 r; r.x = (uint32_t)a; r.y = (uint32_t)c; *reinterpret_cast<u32x2*>(lds + stage32_idx(e)) = r; }
+                        else { u64x2 r; r.x = a; r.y = c; *reinterpret_cast<u64x2*>(lds + stage64_idx(e)) = r; }
                     }
                 } else {
                     for (int i = tid; i < kTile; i += kThreads) {
                         uint64_t r = 0;
-                        if (base + i < jb.n) r = ((uint64_t)x[base + i] - imin) & mask;
-                        if (narrow) stage32[i] = (uint32_t)r; else stage64[i] = r;
+                        if (base + i < jb.n) r = ((uint64_t)ldg<int64_t>(x + base + i) - imin) & mask;
+                        if (narrow) lds[stage32_idx(i)] = (uint32_t)r;
+                        else *reinterpret_cast<uint64_t*>(lds + stage64_idx(i)) = r;
                     }
                 }
-                __syncthreads();
+                lds_barrier();
+                if (narrow) {
+                    uint32_t g[kGroup];
+#pragma unroll
+                    for (int k = 0; k < kGroup / 4; ++k) {
+                        const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+                        g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+                    }
+                    lds_barrier();
+                    pack_group32(g, b, lds + tid * b);
+                } else {
+                    uint64_t g[kGroup];
+#pragma unroll
+                    for (int k = 0; k < kGroup / 2; ++k) {
+                        const u64x2 r = *reinterpret_cast<const u64x2*>(lds + tid * kStride64 + 4 * k);
+                        g[2 * k] = r.x; g[2 * k + 1] = r.y;
+                    }
+                    lds_barrier();
+                    pack_group64(g, b, lds + tid * b);
+                }
+                lds_barrier();
                 const int64_t tile_byte0 = base / 8 * b;
                 int64_t tile_bytes = (int64_t)kTile / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                if (narrow) {
-                    store_tile_words<uint32_t>(stage32, (uint8_t*)jb.dst, tile_byte0, tile_bytes, b, magic);
-                    buf ^= 1;
-                } else {
-                    store_tile_words<uint64_t>(stage64, (uint8_t*)jb.dst, tile_byte0, tile_bytes, b, magic);
-                }
+                store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                lds_barrier();
             }
-            if (!narrow) __syncthreads();
         }
         t0 = tend;
         ++j;
@@ -491,29 +907,51 @@ __global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode pass.  The stream of a block may start at any byte (file offsets are byte granular,
+// decode pass (tile = kTileDD elements).  The stream of a block may start at any byte (file offsets are byte granular,
 // block_index.go:16-23): words are read from the enclosing aligned 64-bit words and funnel-shifted.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t stream_word(const uint64_t* __restrict__ a, int64_t k, int64_t last,
-                                                uint32_t sh) {
-    // a = aligned base, k = word index in the (shifted) stream, last = last aligned word holding data
-    uint64_t lo = k <= last ? a[k] : 0;
-    if (sh == 0) return lo;
-    uint64_t hi = (k + 1) <= last ? a[k + 1] : 0;
-    return (lo >> sh) | (hi << (64 - sh));
+struct StreamView {          // aligned view of a block's packed stream
+    const uint64_t* a;       // enclosing aligned words
+    int64_t last;            // index of the last aligned word that holds stream bytes
+    uint32_t sh;             // bit offset of the stream inside a[0]
+};
+
+__device__ __forceinline__ StreamView stream_view(const DevJob& jb, uint32_t b) {
+    const uintptr_t p = (uintptr_t)jb.src;
+    StreamView v;
+    v.a = reinterpret_cast<const uint64_t*>(p & ~(uintptr_t)7);
+    v.sh = (uint32_t)(p & 7) * 8;
+    const int64_t nbytes = array_bytes(b, jb.n);
+    v.last = (int64_t)(((p + nbytes - 1) & ~(uintptr_t)7) - (p & ~(uintptr_t)7)) >> 3;
+    return v;
 }
 
-// stage the words of one tile (tile = kTile elements = kTile/64*b words) plus one look-ahead word
-__device__ __forceinline__ void stage_tile_words(uint64_t* __restrict__ lw, const DevJob& jb, int64_t base,
-                                                 uint32_t b) {
-    const uintptr_t p = (uintptr_t)jb.src;
-    const uint64_t* a = reinterpret_cast<const uint64_t*>(p & ~(uintptr_t)7);
-    const uint32_t sh = (uint32_t)(p & 7) * 8;
-    const int64_t nbytes = array_bytes(b, jb.n);
-    const int64_t last = (int64_t)(((p + nbytes - 1) & ~(uintptr_t)7) - (p & ~(uintptr_t)7)) >> 3;
+__device__ __forceinline__ uint64_t stream_word(const StreamView& sv, int64_t k) {
+    const uint64_t lo = k <= sv.last ? ldg<uint64_t>(sv.a + k) : 0;
+    if (sv.sh == 0) return lo;
+    const uint64_t hi = (k + 1) <= sv.last ? ldg<uint64_t>(sv.a + k + 1) : 0;
+    return (lo >> sv.sh) | (hi << (64 - sv.sh));
+}
+
+// words of one tile (kTileD elements = kTileD/64*b words, plus one look-ahead word) -> registers
+template <int NW>
+__device__ __forceinline__ void load_tile_words(uint64_t (&w)[NW], const StreamView& sv, int64_t base, uint32_t b) {
     const int64_t w0 = base / 64 * b;
-    const int nw = kTile / 64 * (int)b + 1;
-    for (int w = threadIdx.x; w < nw; w += kThreads) lw[w] = stream_word(a, w0 + w, last, sh);
+    const int nw = kTileD / 64 * (int)b + 1;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int i = k * kThreads + (int)threadIdx.x;
+        w[k] = i < nw ? stream_word(sv, w0 + i) : 0;
+    }
+}
+template <int NW>
+__device__ __forceinline__ void stage_tile_words(uint64_t* __restrict__ lw, const uint64_t (&w)[NW], uint32_t b) {
+    const int nw = kTileD / 64 * (int)b + 1;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int i = k * kThreads + (int)threadIdx.x;
+        if (i < nw) lw[i] = w[k];
+    }
 }
 
 __device__ __forceinline__ uint32_t extract32(const uint32_t* __restrict__ l32, uint32_t i, uint32_t b,
@@ -533,39 +971,48 @@ __device__ __forceinline__ uint64_t extract64(const uint64_t* __restrict__ l64, 
 }
 
 // floatGroup.readData, group.go:299-310.  NARROW: bits <= 32 and min, min+2^bits, pixels fit int32.
+// The next tile's stream words are loaded into registers before the current tile is extracted, and
+// the LDS word buffer is double buffered: one barrier per tile, loads in flight across it.
 template <bool NARROW>
 __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restrict__ jobs, int njobs,
                                                          int64_t total_tiles) {
-    __shared__ __attribute__((aligned(16))) uint64_t lw[kTile / 64 * (NARROW ? 32 : 64) + 2];
+    constexpr int kLW = kTileD / 64 * (NARROW ? 32 : 64) + 2;          // words per LDS buffer
+    constexpr int kNW = (kLW + kThreads - 1) / kThreads;              // words per thread
+    __shared__ __attribute__((aligned(16))) uint64_t lw2[2][kLW];
     const int tid = threadIdx.x;
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
     int j = find_job(jobs, njobs, t0);
+    int buf = 0;
 
     while (t0 < t1) {
         const DevJob jb = jobs[j];
-        const int64_t jend = jb.tile0 + tiles_of(jb.n);
+        const int64_t jend = jb.tile0 + tiles_of_d(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
         float* __restrict__ out = (float*)jb.dst;
         const uint32_t b = (uint32_t)jb.bits;
         const float low = jb.low, dx = jb.dxq;
         const bool per = jb.periodic == 1;
         const uint64_t mask64 = b == 0 ? 0 : (b == 64 ? ~0ull : ((1ull << b) - 1));
+        const StreamView sv = stream_view(jb, b);
+        uint64_t w[kNW];
+        if (b != 0) load_tile_words<kNW>(w, sv, (t0 - jb.tile0) * kTileD, b);
 
         for (int64_t t = t0; t < tend; ++t) {
-            const int64_t base = (t - jb.tile0) * kTile;
+            const int64_t base = (t - jb.tile0) * kTileD;
+            const uint64_t* lw = lw2[buf];
             if (b != 0) {
-                __syncthreads();
-                stage_tile_words(lw, jb, base, b);
-                __syncthreads();
+                stage_tile_words<kNW>(lw2[buf], w, b);
+                if (t + 1 < tend) load_tile_words<kNW>(w, sv, base + kTileD, b);
+                lds_barrier();
             }
             const uint64_t key = dither_key(jb.seed, jb.block, (uint64_t)base >> 32);
             const uint32_t ka = (uint32_t)key, kb = (uint32_t)(key >> 32);
 #pragma unroll
-            for (int k = 0; k < kTile / (4 * kThreads); ++k) {
+            for (int k = 0; k < kTileD / (4 * kThreads); ++k) {
                 const uint32_t i0 = 4 * (k * kThreads + tid);
-                float r[4];
+                f32x4 r;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint32_t i = i0 + c;
@@ -593,56 +1040,64 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
                     r[c] = __fadd_rn(__fmul_rn(dx, (float)__dadd_rn(qd, u)), low);
                 }
                 if (base + i0 + 3 < jb.n) {
-                    *reinterpret_cast<float4*>(out + base + i0) = make_float4(r[0], r[1], r[2], r[3]);
+                    stg<f32x4>(out + base + i0, r);
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) if (base + i0 + c < jb.n) out[base + i0 + c] = r[c];
+                    for (int c = 0; c < 4; ++c) if (base + i0 + c < jb.n) stg<float>(out + base + i0 + c, r[c]);
                 }
             }
+            buf ^= 1;
         }
         t0 = tend;
         ++j;
     }
 }
 
-// intGroup.readData, group.go:257-263; with kind == 0 (raw) it is (*bit.Array).Slice, bit.go:29-82
+// intGroup.readData, group.go:257-263; with min == 0 it is (*bit.Array).Slice, bit.go:29-82
 __global__ __launch_bounds__(kThreads) void k_unpack_i64(const DevJob* __restrict__ jobs, int njobs,
                                                          int64_t total_tiles) {
-    __shared__ __attribute__((aligned(16))) uint64_t lw[kTile / 64 * 64 + 2];
+    constexpr int kLW = kTileD / 64 * 64 + 2;
+    constexpr int kNW = (kLW + kThreads - 1) / kThreads;
+    __shared__ __attribute__((aligned(16))) uint64_t lw2[2][kLW];
     const int tid = threadIdx.x;
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
     int j = find_job(jobs, njobs, t0);
+    int buf = 0;
 
     while (t0 < t1) {
         const DevJob jb = jobs[j];
-        const int64_t jend = jb.tile0 + tiles_of(jb.n);
+        const int64_t jend = jb.tile0 + tiles_of_d(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
         int64_t* __restrict__ out = (int64_t*)jb.dst;
         const uint32_t b = (uint32_t)jb.bits;
         const uint64_t mask64 = b == 0 ? 0 : (b == 64 ? ~0ull : ((1ull << b) - 1));
         const uint64_t mn = (uint64_t)jb.min;
+        const StreamView sv = stream_view(jb, b);
+        uint64_t w[kNW];
+        if (b != 0) load_tile_words<kNW>(w, sv, (t0 - jb.tile0) * kTileD, b);
 
         for (int64_t t = t0; t < tend; ++t) {
-            const int64_t base = (t - jb.tile0) * kTile;
+            const int64_t base = (t - jb.tile0) * kTileD;
+            const uint64_t* lw = lw2[buf];
             if (b != 0) {
-                __syncthreads();
-                stage_tile_words(lw, jb, base, b);
-                __syncthreads();
+                stage_tile_words<kNW>(lw2[buf], w, b);
+                if (t + 1 < tend) load_tile_words<kNW>(w, sv, base + kTileD, b);
+                lds_barrier();
             }
 #pragma unroll
-            for (int k = 0; k < kTile / (2 * kThreads); ++k) {
+            for (int k = 0; k < kTileD / (2 * kThreads); ++k) {
                 const uint32_t i0 = 2 * (k * kThreads + tid);
                 const uint64_t v0 = b == 0 ? 0 : extract64(lw, i0, b, mask64);
                 const uint64_t v1 = b == 0 ? 0 : extract64(lw, i0 + 1, b, mask64);
-                const int64_t r0 = (int64_t)(mn + v0), r1 = (int64_t)(mn + v1);
-                if (base + i0 + 1 < jb.n) {
-                    *reinterpret_cast<longlong2*>(out + base + i0) = make_longlong2(r0, r1);
-                } else if (base + i0 < jb.n) {
-                    out[base + i0] = r0;
-                }
+                i64x2 r;
+                r.x = (int64_t)(mn + v0);
+                r.y = (int64_t)(mn + v1);
+                if (base + i0 + 1 < jb.n) stg<i64x2>(out + base + i0, r);
+                else if (base + i0 < jb.n) stg<int64_t>(out + base + i0, r.x);
             }
+            buf ^= 1;
         }
         t0 = tend;
         ++j;
@@ -731,14 +1186,24 @@ __global__ __launch_bounds__(kThreads) void k_bound_i64(int64_t* __restrict__ q,
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)
 // ------------------------------------------------------------------------------------------------
-void launch_reduce_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, uint64_t* stats) {
-    hipLaunchKernelGGL(k_reduce_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats);
+void launch_reduce_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, uint64_t* stats, void* sync, Meta* meta) {
+    hipLaunchKernelGGL(k_reduce_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, (JobSync*)sync, meta);
 }
 void launch_reduce_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, uint64_t* stats) {
     hipLaunchKernelGGL(k_reduce_i64, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats);
 }
-void launch_pack_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, const uint64_t* stats, Meta* meta) {
-    hipLaunchKernelGGL(k_pack_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, meta);
+void launch_pack_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, void* sync) {
+    hipLaunchKernelGGL(k_pack_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, (JobSync*)sync);
+}
+void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, const int64_t* gtile, const int* gjob, int ngroups,
+                       uint64_t* stats, void* sync, uint32_t* abort_flag, Meta* meta) {
+    hipLaunchKernelGGL(k_encode_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, gtile, gjob, ngroups, stats, (JobSync*)sync, abort_flag, meta);
+}
+size_t job_sync_bytes() { return sizeof(JobSync); }
+int encode_f32_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_f32, kThreads, 0) != hipSuccess) return 0;
+    return n;
 }
 void launch_pack_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, const uint64_t* stats, Meta* meta) {
     hipLaunchKernelGGL(k_pack_i64, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, meta);
