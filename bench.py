@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--group-bytes", type=int, default=0)
+    p.add_argument("--fused", action="store_true", help="float encode as one persistent launch (opt-in)")
     return p.parse_args()
 
 
@@ -54,25 +55,33 @@ def make_column(n, device, seed):
     return x.contiguous()
 
 
-def cpu_baseline(mnw_pixels, n_threads):
+def cpu_baseline(mnw_pixels, n_threads, target_s=12.0):
     """The oracle's LITERAL byte-wise restatement of go/bit + group.go (kind "port": the Go
     reference cannot be built in this image) timed on this host's cores, on a bounded sample of the
-    same workload: each thread encodes and decodes its own blocks of 2^22 elements."""
+    same workload: each thread encodes and decodes its own blocks of 2^22 elements.  The number of
+    blocks per thread is calibrated so that the sample takes about `target_s` seconds."""
     from oracle import oracle as orc
 
     orc.build()
     orc.lib()
-    blk, per_thread = 1 << 22, 8
+    blk = 1 << 22
     rng = np.random.default_rng(0xACEDAD)
     x = np.mod(125 + 20 * rng.standard_normal(blk), 250).astype(np.float32)
     x[x >= np.float32(250.0)] = 0.0
     u = orc.dither(1, 0, blk)
-    orc.float_encode(x[:4096], LOW, HIGH, mnw_pixels, True, literal=True)  # warm the library
+
+    def one():
+        mn, bits, data = orc.float_encode(x, LOW, HIGH, mnw_pixels, True, literal=True)
+        orc.float_decode(data, mn, bits, LOW, HIGH, mnw_pixels, True, blk, u=u, literal=True)
+
+    t0 = time.perf_counter()
+    one()
+    t_one = time.perf_counter() - t0
+    per_thread = max(2, min(200, int(target_s / max(t_one, 1e-3))))
 
     def work():
         for _ in range(per_thread):
-            mn, bits, data = orc.float_encode(x, LOW, HIGH, mnw_pixels, True, literal=True)
-            orc.float_decode(data, mn, bits, LOW, HIGH, mnw_pixels, True, blk, u=u, literal=True)
+            one()
 
     threads = [threading.Thread(target=work) for _ in range(n_threads)]
     t0 = time.perf_counter()
@@ -84,8 +93,8 @@ def cpu_baseline(mnw_pixels, n_threads):
     total_bytes = 4.0 * blk * per_thread * n_threads
     return {
         "value": total_bytes / dt / 1e9, "unit": "GB/s", "cores": n_threads, "kind": "port",
-        "sample": "%d threads x %d blocks of 2^22 float32 (same Gaussian column shape), encode+decode "
-                  "with the literal byte-wise restatement of go/bit + group.go, %.1f s" % (n_threads, per_thread, dt),
+        "sample": "%d threads x %d blocks of 2^22 float32 (same Gaussian column shape), encode+decode with the "
+                  "literal byte-wise restatement of go/bit + group.go, %.1f s" % (n_threads, per_thread, dt),
     }
 
 
@@ -106,6 +115,7 @@ def main():
 
     import minnow_amd as mnw
     from minnow_amd import build as mnw_build
+    from minnow_amd import shard
 
     if rank == 0:
         mnw_build.build()
@@ -125,7 +135,9 @@ def main():
     ctx = mnw.Context(local_rank)
     if a.group_bytes:
         ctx.set_option("group_bytes", a.group_bytes)
-    stream = torch.cuda.current_stream().cuda_stream
+    if a.fused:
+        ctx.set_option("fused", 1)
+    stream = None   # the context's own stream; torch.cuda.synchronize() below is device wide
 
     enc_jobs = [mnw.EncJob(x.data_ptr() + 4 * k * B, packed.data_ptr() + k * slot, min(B, N - k * B), slot,
                            mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1) for k in range(nblk)]
@@ -149,11 +161,7 @@ def main():
         metas = step()
     sync_all()
 
-    # ---- timed region: exactly K steps --------------------------------------------------------
-    timing = not a.no_kernel_timing
-    if timing:
-        ctx.timing_enable(True)
-        ctx.timing_reset()
+    # ---- timed region: exactly K steps, no instrumentation ------------------------------------------
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -163,14 +171,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ktimes = ctx.timing_get() if timing else {}
-    if timing:
-        ctx.timing_enable(False)
+    dt = shard.max_over_ranks(dt, device=device)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- the same K steps again with a HIP event pair around every kernel launch, recorded on the
+    # stream the kernel is launched on (the context's stream).  Kept out of the region above because
+    # the event records add a few microseconds per launch to the host-inclusive time.
+    timing = not a.no_kernel_timing
+    ktimes = {}
+    if timing:
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        ktimes = ctx.timing_get()
+        ctx.timing_enable(False)
 
     # separate, un-instrumented encode-only / decode-only timings (reported, not `value`)
     def time_only(fn, reps):
@@ -217,35 +232,51 @@ def main():
     }
 
     # ---- roofline: algorithmic bytes / HIP-event kernel time, per launch ---------------------------
+    # float encode = (4 + b/8) B per element: one read of the block, one write of the stream
+    # (SURVEY.md 8d); it takes two launches per batch (reduce + pack), so its device time is their sum.
+    # float decode = (b/8 + 4) B per element, one launch.
     if timing and ktimes:
         steps = a.steps
-        red, pk, up = ktimes.get("k_reduce_f32"), ktimes.get("k_pack_f32"), ktimes.get("k_unpack_f32")
-        enc_alg = in_bytes + packed_bytes                     # (4 + b/8) B/elt, one read + one write
-        dec_alg = packed_bytes + in_bytes                     # (b/8 + 4) B/elt
-        enc_ms = (red["total_ms"] + pk["total_ms"]) / steps   # device time of one column encode
-        dec_ms = up["total_ms"] / steps
-        kern = []
-        for name, kt, alg in (("k_reduce_f32", red, None), ("k_pack_f32", pk, None), ("k_unpack_f32", up, dec_alg)):
-            if kt and kt["launches"]:
-                kern.append({"kernel": name, "launches": kt["launches"], "avg_us": 1e3 * kt["total_ms"] / kt["launches"]})
+
+        def avg_us(name):
+            kt = ktimes.get(name)
+            return (1e3 * kt["total_ms"] / kt["launches"], kt["launches"]) if kt and kt["launches"] else (0.0, 0)
+
+        enc_alg = in_bytes + packed_bytes
+        dec_alg = packed_bytes + in_bytes
+        enc_names = ["k_encode_f32"] if a.fused else ["k_reduce_f32", "k_pack_f32"]
+        enc_ms = sum(ktimes[k]["total_ms"] for k in enc_names if k in ktimes) / steps
+        dec_ms = ktimes["k_unpack_f32"]["total_ms"] / steps
         enc_ach = enc_alg / (enc_ms * 1e-3) / 1e9
         dec_ach = dec_alg / (dec_ms * 1e-3) / 1e9
+        launches_per_step = ktimes[enc_names[-1]]["launches"] / steps
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_reduce_f32+k_pack_f32 (float encode = two launches per block group)",
+            "bound": "hbm", "kernel": "+".join(enc_names) + " (float encode)",
             "achieved": enc_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc_ach / HBM_PEAK_GBPS,
             "traffic": None,
-            "algorithmic_bytes_per_elt": (in_bytes + packed_bytes) / N,
-            "elements_per_launch": N / (pk["launches"] / steps),
-            "avg_launch_us": {"k_reduce_f32": 1e3 * red["total_ms"] / red["launches"],
-                              "k_pack_f32": 1e3 * pk["total_ms"] / pk["launches"]},
+            "algorithmic_bytes_per_elt": enc_alg / N,
+            "elements_per_launch": N / launches_per_step,
+            "avg_launch_us": {k: avg_us(k)[0] for k in enc_names},
+            "note": "achieved = (4 + b/8) B/elt x elements per batch / summed HIP-event time of the encode launches",
         }
         out["roofline_decode"] = {
             "bound": "hbm", "kernel": "k_unpack_f32", "achieved": dec_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": dec_ach / HBM_PEAK_GBPS, "traffic": None,
-            "algorithmic_bytes_per_elt": dec_alg / N,
-            "avg_launch_us": 1e3 * up["total_ms"] / up["launches"],
+            "frac": dec_ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_elt": dec_alg / N,
+            "avg_launch_us": avg_us("k_unpack_f32")[0],
         }
-        out["kernels"] = kern
+        out["kernels"] = [{"kernel": k, "launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / v["launches"]}
+                          for k, v in ktimes.items() if v["launches"]]
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            # HBM bytes per launch from rocprofv3 --pmc passes (collected separately; see profiles/README.md)
+            try:
+                with open(pmc) as f:
+                    t = json.load(f)
+                out["roofline"]["traffic"] = t.get("encode_bytes_per_batch")
+                out["roofline_decode"]["traffic"] = t.get("decode_bytes_per_batch")
+                out["roofline"]["traffic_source"] = t.get("source")
+            except Exception:
+                pass
 
     if world == 1 and not a.no_cpu_baseline:
         ncpu = os.cpu_count() or 1

@@ -12,6 +12,7 @@
 #include <vector>
 
 namespace mnw {
+void launch_prepare(hipStream_t, const void*, void*, int64_t, void*, int64_t, void*, int64_t);
 void launch_reduce_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*, void*, Meta*);
 size_t job_sync_bytes();
 void launch_reduce_i64(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
@@ -40,19 +41,27 @@ constexpr int kSlots = 3;
 constexpr int kSyncPad = 32;      // keeps the abort flag on its own 128-byte line
 struct JobSlot {
     int cap = 0;
+    // upload block: one pinned host allocation and its device mirror with the same layout
+    // [DevJob x cap][gtile: int64 x (cap+1)][gjob: int x (cap+2)]; k_prepare copies it in one launch
+    uint8_t* h_up = nullptr;
+    uint8_t* d_up = nullptr;
+    size_t up_bytes = 0;
     DevJob* d_jobs = nullptr;
-    DevJob* h_jobs = nullptr;     // pinned
-    uint64_t* d_stats = nullptr;
-    Meta* d_meta = nullptr;
-    Meta* h_meta = nullptr;       // pinned
+    DevJob* h_jobs = nullptr;
     int64_t* d_gtile = nullptr;   // fused encode: group boundaries in the batch-wide tile numbering
-    int64_t* h_gtile = nullptr;   // pinned
+    int64_t* h_gtile = nullptr;
     int* d_gjob = nullptr;        // fused encode: first job of each group
-    int* h_gjob = nullptr;        // pinned
-    uint8_t* d_sync = nullptr;    // per-job arrival count + published descriptor word (mnw::JobSync), then
-                                  // kSyncPad words whose first is the fused launch's abort flag
-    uint32_t* h_sync = nullptr;   // pinned: abort flag read back with the metadata
+    int* h_gjob = nullptr;
+    // work block (device): [stats x cap][abort pad][JobSync x cap]; k_prepare zeroes the used parts
+    uint64_t* d_stats = nullptr;
+    uint8_t* d_sync = nullptr;    // kSyncPad words (the first is the fused launch's abort flag), then one
+                                  // mnw::JobSync (arrival count + published descriptor word) per job
     size_t sync_stride = 64;
+    // results: pinned host memory the kernels write directly (no device-to-host copy)
+    Meta* h_meta = nullptr;
+    Meta* d_meta = nullptr;       // device address of h_meta
+    uint32_t* h_sync = nullptr;   // abort flag of the fused launch, copied here by a 1-word k_prepare
+    uint32_t* d_hsync = nullptr;  // device address of h_sync
     hipEvent_t consumed = nullptr;
     bool in_flight = false;
 };
@@ -122,12 +131,10 @@ int fail(mnw_ctx* c, int status, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 void free_slot(JobSlot& sl) {
-    if (sl.d_jobs) {
-        hipFree(sl.d_jobs); hipFree(sl.d_stats); hipFree(sl.d_meta); hipHostFree(sl.h_jobs); hipHostFree(sl.h_meta);
-        hipFree(sl.d_gtile); hipHostFree(sl.h_gtile); hipFree(sl.d_gjob); hipHostFree(sl.h_gjob);
-        hipFree(sl.d_sync); hipHostFree(sl.h_sync);
+    if (sl.d_up) {
+        hipFree(sl.d_up); hipHostFree(sl.h_up); hipFree(sl.d_stats); hipHostFree(sl.h_meta); hipHostFree(sl.h_sync);
     }
-    sl.d_jobs = nullptr; sl.cap = 0;
+    sl.d_up = nullptr; sl.d_jobs = nullptr; sl.cap = 0;
 }
 
 // next ring slot with room for n jobs; waits (host side) only if that slot's previous batch is
@@ -142,28 +149,39 @@ int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
         int cap = sl.cap ? sl.cap : 64;
         while (cap < n) cap *= 2;
         free_slot(sl);
-        HIPCHK(c, hipMalloc((void**)&sl.d_jobs, sizeof(DevJob) * cap));
-        HIPCHK(c, hipMalloc((void**)&sl.d_stats, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * cap));
-        HIPCHK(c, hipMalloc((void**)&sl.d_meta, sizeof(Meta) * cap));
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_jobs, sizeof(DevJob) * cap, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocDefault));
-        HIPCHK(c, hipMalloc((void**)&sl.d_gtile, sizeof(int64_t) * (cap + 1)));
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_gtile, sizeof(int64_t) * (cap + 1), hipHostMallocDefault));
-        HIPCHK(c, hipMalloc((void**)&sl.d_gjob, sizeof(int) * (cap + 1)));
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_gjob, sizeof(int) * (cap + 1), hipHostMallocDefault));
+        const size_t off_gtile = sizeof(DevJob) * cap;
+        const size_t off_gjob = off_gtile + sizeof(int64_t) * (cap + 1);
+        sl.up_bytes = (off_gjob + sizeof(int) * (cap + 2) + 15) / 16 * 16;
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_up, sl.up_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void**)&sl.d_up, sl.up_bytes));
+        memset(sl.h_up, 0, sl.up_bytes);
+        sl.h_jobs = (DevJob*)sl.h_up; sl.d_jobs = (DevJob*)sl.d_up;
+        sl.h_gtile = (int64_t*)(sl.h_up + off_gtile); sl.d_gtile = (int64_t*)(sl.d_up + off_gtile);
+        sl.h_gjob = (int*)(sl.h_up + off_gjob); sl.d_gjob = (int*)(sl.d_up + off_gjob);
         sl.sync_stride = mnw::job_sync_bytes();
-        HIPCHK(c, hipMalloc((void**)&sl.d_sync, sl.sync_stride * cap + sizeof(uint32_t) * kSyncPad));
+        const size_t stats_bytes = sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * cap;
+        HIPCHK(c, hipMalloc((void**)&sl.d_stats, stats_bytes + sizeof(uint32_t) * kSyncPad + sl.sync_stride * cap));
+        sl.d_sync = (uint8_t*)sl.d_stats + stats_bytes;
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc((void**)&sl.h_sync, sizeof(uint32_t) * kSyncPad, hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&sl.d_meta, sl.h_meta, 0));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&sl.d_hsync, sl.h_sync, 0));
         sl.cap = cap;
     }
     *out = &sl;
     return MNW_OK;
 }
 
-uint32_t* abort_ptr(JobSlot* sl) { return (uint32_t*)(sl->d_sync + sl->sync_stride * sl->cap); }
-int clear_sync(mnw_ctx* c, JobSlot* sl, hipStream_t s, int njobs) {
-    HIPCHK(c, hipMemsetAsync(sl->d_sync, 0, sl->sync_stride * njobs, s));
-    HIPCHK(c, hipMemsetAsync(abort_ptr(sl), 0, sizeof(uint32_t) * kSyncPad, s));
+uint32_t* abort_ptr(JobSlot* sl) { return (uint32_t*)sl->d_sync; }
+void* sync_ptr(JobSlot* sl, int j) { return sl->d_sync + sizeof(uint32_t) * kSyncPad + sl->sync_stride * j; }
+
+// One small launch sets a batch up: job records (and group tables) from pinned host memory into
+// device memory, statistics and synchronisation words of the first njobs jobs zeroed.
+int prepare_slot(mnw_ctx* c, JobSlot* sl, hipStream_t s, int njobs, bool zero) {
+    mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
+                        zero ? sl->d_stats : nullptr, zero ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * njobs) : 0,
+                        zero ? sl->d_sync : nullptr, zero ? (int64_t)(sizeof(uint32_t) * kSyncPad + sl->sync_stride * njobs) : 0);
+    HIPCHK(c, hipGetLastError());
     return MNW_OK;
 }
 
@@ -290,7 +308,7 @@ int launch_encode_range(mnw_ctx* c, JobSlot* sl, hipStream_t s, int j0, int j1, 
             const int grid = grid_for(c, tiles);
             uint64_t* st = sl->d_stats + (size_t)g0 * mnw::kStatSlots * mnw::kStatWords;
             if (kind == MNW_FLOAT_GROUP) {
-                void* sy = sl->d_sync + sl->sync_stride * g0;
+                void* sy = sync_ptr(sl, g0);
                 { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs + g0, g1 - g0, tiles, st, sy, sl->d_meta + g0); }
                 { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, pack_grid_for(c, tiles), sl->d_jobs + g0, g1 - g0, tiles, sy); }
             } else {
@@ -306,7 +324,7 @@ int launch_encode_range(mnw_ctx* c, JobSlot* sl, hipStream_t s, int j0, int j1, 
 
 // One persistent launch for all float jobs [0, nfloat) of the slot (k_encode_f32).  Groups follow
 // the same rule as launch_encode_range; tile0 here is batch-wide, not group relative.
-int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat) {
+int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
     if (c->fused_blocks_per_cu == 0) {
         int occ = mnw::encode_f32_blocks_per_cu();
         // the occupancy API can over-report by one block per CU for SGPR-heavy kernels
@@ -333,14 +351,14 @@ int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat) {
     sl->h_gtile[ng] = tiles;
     sl->h_gjob[ng] = nfloat;
     if (tiles == 0) return MNW_OK;
-    HIPCHK(c, hipMemcpyAsync(sl->d_gtile, sl->h_gtile, sizeof(int64_t) * (ng + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(sl->d_gjob, sl->h_gjob, sizeof(int) * (ng + 1), hipMemcpyHostToDevice, s));
+    int rc = prepare_slot(c, sl, s, nslot_all, true);
+    if (rc) return rc;
     int grid = c->cus * c->fused_blocks_per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
     { ScopedTimer t(c, s, MNW_K_ENCODE_F32);
-      mnw::launch_encode_f32(s, grid, sl->d_jobs, nfloat, sl->d_gtile, sl->d_gjob, ng, sl->d_stats, sl->d_sync, abort_ptr(sl), sl->d_meta); }
+      mnw::launch_encode_f32(s, grid, sl->d_jobs, nfloat, sl->d_gtile, sl->d_gjob, ng, sl->d_stats, sync_ptr(sl, 0), abort_ptr(sl), sl->d_meta); }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(sl->h_sync, abort_ptr(sl), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    mnw::launch_prepare(s, abort_ptr(sl), sl->d_hsync, 4, nullptr, 0, nullptr, 0);   // abort flag -> pinned host word
     return MNW_OK;
 }
 
@@ -353,21 +371,18 @@ int encode_one_sync(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, int mode,
     DevJob& d = sl->h_jobs[0];
     fill_enc(d, job);
     d.mode = mode; d.min = emin; d.bits = ebits; d.tile0 = 0;
-    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob), hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords, s));
-    rc = clear_sync(c, sl, s, 1);
+    rc = prepare_slot(c, sl, s, 1, true);
     if (rc) return rc;
     const int64_t tiles = (job.n + mnw::kTile - 1) / mnw::kTile;
     const int grid = grid_for(c, tiles);
     if (job.kind == MNW_FLOAT_GROUP) {
-        { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_sync, sl->d_meta); }
-        { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, pack_grid_for(c, tiles), sl->d_jobs, 1, tiles, sl->d_sync); }
+        { ScopedTimer t(c, s, MNW_K_REDUCE_F32); mnw::launch_reduce_f32(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sync_ptr(sl, 0), sl->d_meta); }
+        { ScopedTimer t(c, s, MNW_K_PACK_F32); mnw::launch_pack_f32(s, pack_grid_for(c, tiles), sl->d_jobs, 1, tiles, sync_ptr(sl, 0)); }
     } else {
         if (mode == mnw::kModeStats) { ScopedTimer t(c, s, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats); }
         { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid, sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *out = sl->h_meta[0];
     return MNW_OK;
@@ -593,22 +608,18 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
             int64_t tiles = 0;
             for (int k = 0; k < nfloat; ++k) { sl->h_jobs[k].tile0 = tiles; tiles += (sl->h_jobs[k].n + mnw::kTile - 1) / mnw::kTile; }
         }
-        HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot, s));
-        rc = clear_sync(c, sl, s, nslot);
-        if (rc) return rc;
         c->pend_fused = fused;
         c->pend_nfloat = nfloat;
         if (fused) {
-            HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
-            rc = launch_encode_fused(c, sl, s, nfloat);
+            rc = launch_encode_fused(c, sl, s, nfloat, nslot);        // its k_prepare covers all nslot jobs
         } else {
-            HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+            rc = prepare_slot(c, sl, s, nslot, true);
+            if (rc) return rc;
             rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
         }
         if (rc) return rc;
         rc = launch_encode_range(c, sl, s, nfloat, nslot, MNW_INT_GROUP);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta) * nslot, hipMemcpyDeviceToHost, s));
     }
     rc = release_slot(c, sl, s);
     if (rc) return rc;
@@ -642,13 +653,10 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
             }
             g0 = g1;
         }
-        HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * c->pend_nfloat, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemsetAsync(sl->d_stats, 0, sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * c->pend_nfloat, s));
-        int rc = clear_sync(c, sl, s, c->pend_nfloat);
+        int rc = prepare_slot(c, sl, s, c->pend_nfloat, true);
         if (rc) return rc;
         rc = launch_encode_range(c, sl, s, 0, c->pend_nfloat, MNW_FLOAT_GROUP);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(sl->h_meta, sl->d_meta, sizeof(Meta) * c->pend_nfloat, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
     }
     std::vector<Meta> res(njobs);
@@ -717,7 +725,8 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     }
     cls_begin[3] = nslot;
     if (nslot == 0) return MNW_OK;
-    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob) * nslot, hipMemcpyHostToDevice, s));
+    rc = prepare_slot(c, sl, s, nslot, false);
+    if (rc) return rc;
     for (int cls = 0; cls < 3; ++cls) {
         const int j0 = cls_begin[cls], j1 = cls_begin[cls + 1];
         if (j1 == j0) continue;
@@ -746,7 +755,8 @@ int mnw_pack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint64_t* x, int64_t
     memset(&d, 0, sizeof d);
     d.src = x; d.dst = out; d.n = n; d.cap = cap; d.kind = MNW_INT_GROUP;
     d.mode = mnw::kModeExplicit; d.min = 0; d.bits = bits; d.tile0 = 0;
-    HIPCHK(c, hipMemcpyAsync(sl->d_jobs, sl->h_jobs, sizeof(DevJob), hipMemcpyHostToDevice, s));
+    rc = prepare_slot(c, sl, s, 1, false);
+    if (rc) return rc;
     const int64_t tiles = (n + mnw::kTile - 1) / mnw::kTile;
     { ScopedTimer t(c, s, MNW_K_PACK_I64); mnw::launch_pack_i64(s, grid_for(c, tiles), sl->d_jobs, 1, tiles, sl->d_stats, sl->d_meta); }
     HIPCHK(c, hipGetLastError());

@@ -1184,8 +1184,32 @@ __global__ __launch_bounds__(kThreads) void k_bound_i64(int64_t* __restrict__ q,
 }
 
 // ------------------------------------------------------------------------------------------------
+// batch set-up in ONE small launch: copy the job records (and the fused launch's group tables) out of
+// host-pinned memory and zero the batch's statistics / synchronisation words.  This replaces a
+// host-to-device copy plus several memsets, each of which is a separate engine command with its own
+// cross-queue dependency (tens of microseconds per batch).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                      int64_t copy_words, uint32_t* __restrict__ zero0, int64_t zero0_words,
+                                                      uint32_t* __restrict__ zero1, int64_t zero1_words) {
+    const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, step = (int64_t)gridDim.x * kThreads;
+    for (int64_t i = i0; i < copy_words; i += step) dst[i] = src[i];
+    for (int64_t i = i0; i < zero0_words; i += step) zero0[i] = 0;
+    for (int64_t i = i0; i < zero1_words; i += step) zero1[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)
 // ------------------------------------------------------------------------------------------------
+void launch_prepare(hipStream_t s, const void* src, void* dst, int64_t copy_bytes, void* zero0, int64_t zero0_bytes,
+                    void* zero1, int64_t zero1_bytes) {
+    const int64_t words = (copy_bytes + zero0_bytes + zero1_bytes) / 4;
+    int grid = (int)((words + kThreads * 4 - 1) / (kThreads * 4));
+    if (grid < 1) grid = 1;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(k_prepare, dim3(grid), dim3(kThreads), 0, s, (const uint32_t*)src, (uint32_t*)dst, copy_bytes / 4,
+                       (uint32_t*)zero0, zero0_bytes / 4, (uint32_t*)zero1, zero1_bytes / 4);
+}
 void launch_reduce_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, uint64_t* stats, void* sync, Meta* meta) {
     hipLaunchKernelGGL(k_reduce_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, (JobSync*)sync, meta);
 }
