@@ -164,6 +164,7 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_UNPACK_F32  4
 #define MNW_K_UNPACK_I64  5
 #define MNW_K_ENCODE_F32  6   /* fused float encode: reduce + pack of a whole batch in one persistent launch */
+#define MNW_K_ENCODE_REG_F32 7 /* single-read float encode: the block stays in registers between reduce and pack */
 #define MNW_K_COUNT       8
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
@@ -178,6 +179,8 @@ const char *mnw_kernel_name(int kernel_id);
  * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM.
  * fused: 1 = float batches run as one persistent launch (k_encode_f32), 0 (default) = one reduce and one
  *        pack launch per group.
+ * single_read: 1 = float blocks of at most 2^24 elements are encoded by k_encode_reg_f32, which reads each
+ *        block once and keeps it in registers; 0 (default) = the reduce + pack launches.
  * grid_cap: upper bound on workgroups per launch. */
 int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
 

@@ -20,6 +20,8 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*, void*, uint32_t*, Meta*);
+int encode_reg_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
@@ -100,6 +102,9 @@ struct mnw_ctx {
     int64_t group_bytes = 1ll << 40;   // two-kernel path: all blocks of a batch in one reduce + one pack launch
     int grid_cap = 0;
     int fused = 0;               // float encode as one persistent launch per batch (k_encode_f32): opt-in, see DESIGN.md
+    int single_read = 0;         // float encode through k_encode_reg_f32 (block read once): opt-in, see DESIGN.md
+    int reg_blocks_per_cu = 0;   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
+    int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
     int fused_blocks_per_cu = 0; // co-resident workgroups of k_encode_f32 per CU (occupancy query)
     int64_t fused_aborts = 0;    // fused launches that fell back to the two-kernel path
     int pend_nfloat = 0;         // device slots [0, pend_nfloat) of the pending batch are float jobs
@@ -362,6 +367,36 @@ int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int 
     return MNW_OK;
 }
 
+// Single-read float encode (k_encode_reg_f32) for the float jobs [0, nfloat) of the slot.  Only legal
+// when every block has at most `grid` items (see the kernel's header); returns 1 if not eligible.
+int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
+    if (c->reg_blocks_per_cu == 0) {
+        int occ = mnw::encode_reg_f32_blocks_per_cu();
+        c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);
+    }
+    if (c->reg_blocks_per_cu < 1) return 1;
+    int grid = c->cus * c->reg_blocks_per_cu;
+    if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
+    const int64_t item = 2 * mnw::kTile;
+    int64_t items = 0;
+    for (int k = 0; k < nfloat; ++k) {
+        const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
+        if (ni > grid) return 1;
+        sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
+        items += ni;
+    }
+    int rc = prepare_slot(c, sl, s, nslot_all, true);
+    if (rc) return rc;
+    if (items > 0) {
+        if (items < grid) grid = (int)items;
+        ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
+        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_stats, sync_ptr(sl, 0), abort_ptr(sl), sl->d_meta);
+    }
+    HIPCHK(c, hipGetLastError());
+    mnw::launch_prepare(s, abort_ptr(sl), sl->d_hsync, 4, nullptr, 0, nullptr, 0);   // abort flag -> pinned host word
+    return MNW_OK;
+}
+
 // Encode int64 blocks that already sit in device memory, synchronously (used by the exact path and
 // by the host-pointer entry points).  Uses device job slot 0.
 int encode_one_sync(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, int mode, int64_t emin, int ebits, Meta* out) {
@@ -456,6 +491,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_UNPACK_F32: return "k_unpack_f32";
         case MNW_K_UNPACK_I64: return "k_unpack_i64";
         case MNW_K_ENCODE_F32: return "k_encode_f32";
+        case MNW_K_ENCODE_REG_F32: return "k_encode_reg_f32";
         default: return "";
     }
 }
@@ -498,6 +534,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return MNW_E_ARG;
     if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (1ll << 40); return MNW_OK; }
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
+    if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
     return fail(c, MNW_E_ARG, "unknown option");
 }
@@ -610,7 +647,20 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
         }
         c->pend_fused = fused;
         c->pend_nfloat = nfloat;
-        if (fused) {
+        c->pend_mode = fused ? 1 : 0;
+        rc = 1;
+        if (!fused && c->single_read && nfloat > 0) {
+            // keep the group-relative numbering in case the batch is not eligible
+            std::vector<int64_t> keep(nfloat);
+            for (int k = 0; k < nfloat; ++k) keep[k] = sl->h_jobs[k].tile0;
+            rc = launch_encode_reg(c, sl, s, nfloat, nslot);
+            if (rc == 1) for (int k = 0; k < nfloat; ++k) sl->h_jobs[k].tile0 = keep[k];
+            else if (rc == MNW_OK) c->pend_mode = 2;
+            else return rc;
+        }
+        if (rc == MNW_OK) {
+            // launched above
+        } else if (fused) {
             rc = launch_encode_fused(c, sl, s, nfloat, nslot);        // its k_prepare covers all nslot jobs
         } else {
             rc = prepare_slot(c, sl, s, nslot, true);
@@ -638,7 +688,7 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(s));
     const int njobs = (int)c->pend_jobs.size();
-    if (c->pend_fused && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
+    if (c->pend_mode != 0 && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
         // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
         // part of the GPU): rerun the float jobs through the two-kernel path.  Still the GPU path.
         c->fused_aborts++;

@@ -239,7 +239,9 @@ struct Pending {
 // wave 0 only.  The block is complete with this arrival: derive its descriptor once, publish it as
 // one 8-byte word and write the block's metadata.  Every other producer drained its statistics
 // atomics before counting in, so agent-scope loads see all of them.
-__device__ __forceinline__ void finalize_job_f32(const DevJob* __restrict__ jobs, int j, const uint64_t* __restrict__ stats,
+// (not inlined: it runs once per block, and inlined its float64 temporaries would raise the register
+// count of every kernel that can complete a block)
+__device__ __attribute__((noinline)) void finalize_job_f32(const DevJob* __restrict__ jobs, int j, const uint64_t* __restrict__ stats,
                                                  JobSync* __restrict__ sync, Meta* __restrict__ meta) {
     const DevJob jb = jobs[j];
     uint64_t st[5];
@@ -543,6 +545,13 @@ __device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out,
     }
 }
 
+// true for a NONZERO quotient below the float32 normal range, where the float64-multiply argument does
+// not apply.  Zero needs no redo: t == 0 gives 0 either way, and a float32 divisor is never within 2^-52
+// (relative) of the even integer a product rounding to zero against a quotient of 2^-149 would need.
+__device__ __forceinline__ bool quant_tiny(float r) {
+    return ((__float_as_uint(r) & 0x7fffffffu) - 1u) < 0x007fffffu;
+}
+
 // go/group.go:318-319 with the division done as a float64 multiply by 1/dx.  For float32 t, dx the
 // value RN32(RN64(double(t) * RN64(1/double(dx)))) equals the correctly rounded float32 quotient:
 // the double product is within 2^-52 (relative) of t/dx, and a quotient of two 24-bit significands is
@@ -551,7 +560,7 @@ __device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out,
 __device__ __forceinline__ float quant_floor_fast(float x, float low, float dx, double rdx) {
     const float t = __fsub_rn(x, low);
     float r = (float)__dmul_rn((double)t, rdx);
-    if (__builtin_expect(fabsf(r) < 1.17549435e-38f, 0)) r = __fdiv_rn(t, dx);
+    if (__builtin_expect(quant_tiny(r), 0)) r = __fdiv_rn(t, dx);
     return floorf(r);
 }
 
@@ -559,6 +568,7 @@ __device__ __forceinline__ float quant_floor_fast(float x, float low, float dx, 
 __device__ __forceinline__ float quant_mul(float x, float low, double rdx) {
     return (float)__dmul_rn((double)__fsub_rn(x, low), rdx);
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // pack pass, float32 blocks (32-bit path: q in [0,pixels), pixels < 2^31, or int32-range q when
@@ -676,7 +686,7 @@ __device__ __forceinline__ bool pack_range_f32(uint32_t* __restrict__ lds, uint6
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float rq = quant_mul(v[k][c], low, rdx);
-                            tiny |= fabsf(rq) < 1.17549435e-38f;
+                            tiny |= quant_tiny(rq);
                             const int32_t q = (int32_t)floorf(rq);
                             uint32_t uq = (uint32_t)q;
                             if (per && q < pmin) uq += pix;         // bound(), group.go:374-382
@@ -815,6 +825,194 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
         if (g >= 1 && !(dbg_skip & 2)) {
             if (!pack_range_f32<true>(lds, &shared_slot, jobs, gjob[g - 1], gjob[g], pa, pb, sync, abort_flag, pref,
                                       &pend, stats, meta)) return;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-read float32 encode (k_encode_reg_f32): the block is read ONCE.
+//
+// An item = 16,384 consecutive elements of one block = 64 values per lane, which stay in registers
+// from the load to the pack.  Workgroup w takes items w, w+G, w+2G, ... of the batch-wide item
+// numbering.  Per item: load -> fold the raw floats into the block's statistics (as k_reduce_f32) ->
+// count the item in -> [the workgroup whose count completes the block publishes its descriptor word]
+// -> wait for that word -> re-base, pack and store from the registers (two 8,192-element pack tiles).
+// While wave 0 runs the count-in round trips the other waves already turn their floats into pixel
+// indices (the float64 multiply, floor and convert need nothing from the descriptor).
+//
+// No deadlock if every block has at most G items and all G workgroups are resident: let m be the
+// smallest item any workgroup is blocked on.  Every item k of m's block is either < m (its owner has
+// moved past it, so it was counted in) or in (m, m+G): its owner handles items congruent to k mod G in
+// increasing order and is blocked on an item >= m, which can only be k itself or a later one -- and a
+// workgroup counts an item in BEFORE it waits for that item's block.  So the block is complete and its
+// last arrival has published the descriptor.  The host only sends blocks of at most G items here
+// (G x 16,384 = 2^24 elements at 4 workgroups per CU) and sizes G from the occupancy query; spins are
+// bounded and a timeout aborts the launch (the host then reruns the batch through the two-kernel path).
+// HBM traffic = algorithmic bytes: 4 B/element read + b/8 B/element written.
+// ------------------------------------------------------------------------------------------------
+constexpr int kItem = 2 * kTile;
+__device__ __forceinline__ int64_t items_of(int64_t n) { return (n + kItem - 1) / kItem; }
+
+// job of item t (DevJob.tile0 holds the job's first ITEM in this launch's numbering)
+__device__ __forceinline__ int find_job_item(const DevJob* jobs, int lo, int njobs, int64_t t) {
+    int hi = njobs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kThreads, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
+                                                             int64_t total_items, uint64_t* __restrict__ stats,
+                                                             JobSync* __restrict__ sync, uint32_t* __restrict__ abort_flag,
+                                                             Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds32 / 4];
+    __shared__ float red[4][kThreads / 64];
+    __shared__ int redbad[kThreads / 64];
+    __shared__ uint64_t shared_slot;
+    constexpr int kV = kItem / (4 * kThreads);         // 16-byte loads per lane per item (16)
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.x % kStatSlots;
+    int j = 0;
+
+    for (int64_t it = blockIdx.x; it < total_items; it += gridDim.x) {
+        j = find_job_item(jobs, j, njobs, it);
+        const DevJob jb = jobs[j];
+        const float* __restrict__ x = (const float*)jb.src;
+        const int64_t base = (it - jb.tile0) * kItem;
+        const bool full = base + kItem <= jb.n;
+
+        // ---- load + statistics -------------------------------------------------------------------
+        // e[] holds the lane's 64 elements: first the raw float bits, later (in place) their pixel indices
+        u32x4 e[kV];
+        FStat s = {INFINITY, -INFINITY, -INFINITY, INFINITY, false};
+        const float xh = jb.xh;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(x + base + 4 * (k * kThreads + tid));
+#pragma unroll
+            for (int k = 0; k < kV; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fstat_add(s, __uint_as_float(e[k][c]), xh);
+            }
+        } else {
+            for (int64_t i = base + tid; i < jb.n; i += kThreads) fstat_add(s, ldg<float>(x + i), xh);
+        }
+        float mn = wave_min(s.mn), mx = wave_max(s.mx), mxlo = wave_max(s.mxlo), mnhi = wave_min(s.mnhi);
+        int bad = __any(s.bad);
+        __syncthreads();
+        if (lane_id() == 0) {
+            red[0][wave_id()] = mn; red[1][wave_id()] = mx;
+            red[2][wave_id()] = mxlo; red[3][wave_id()] = mnhi;
+            redbad[wave_id()] = bad;
+        }
+        __syncthreads();
+
+        // ---- wave 0: publish the statistics, count the item in, finalize the block if it is complete.
+        //      waves 1-3 meanwhile: floats -> pixel indices (descriptor independent part of the quantize)
+        const float low = jb.low, dx = jb.dxq;
+        const double rdx = jb.rdx;
+        bool tiny = false;
+        if (wave_id() == 0) {
+            if (tid < 5) {
+                float a = red[0][0], b = red[1][0], c2 = red[2][0], dd = red[3][0];
+                int bd = redbad[0];
+#pragma unroll
+                for (int w = 1; w < kThreads / 64; ++w) {
+                    a = fminf(a, red[0][w]); b = fmaxf(b, red[1][w]);
+                    c2 = fmaxf(c2, red[2][w]); dd = fminf(dd, red[3][w]);
+                    bd |= redbad[w];
+                }
+                uint64_t val;
+                if (tid == 0) val = bd ? 0 : fkey(b);
+                else if (tid == 1) val = bd ? 0 : (uint32_t)~fkey(a);
+                else if (tid == 2) val = (bd || c2 == -INFINITY) ? 0 : fkey(c2);
+                else if (tid == 3) val = (bd || dd == INFINITY) ? 0 : (uint32_t)~fkey(dd);
+                else val = bd ? 1 : 0;
+                uint64_t* rec = stats + ((int64_t)j * kStatSlots + slot) * kStatWords;
+                if (val != 0) atomicMax((unsigned long long*)(rec + tid), (unsigned long long)val);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // statistics drained
+            uint32_t before = 0;
+            if (tid == 0) before = __hip_atomic_fetch_add(&sync[j].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before = __builtin_amdgcn_readfirstlane(before);
+            if (before + 1 == (uint32_t)items_of(jb.n)) finalize_job_f32(jobs, j, stats, sync, meta);
+        }
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < kV; ++k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float rq = quant_mul(__uint_as_float(e[k][c]), low, rdx);
+                    tiny |= quant_tiny(rq);
+                    e[k][c] = (uint32_t)(int32_t)floorf(rq);
+                }
+            }
+        }
+
+        // ---- the block's descriptor ----------------------------------------------------------------
+        uint64_t gran;
+        if (!get_granule<true>(sync, abort_flag, j, 0, &shared_slot, &gran)) return;
+        const Desc d = gran_decode(gran, jb.n);
+        const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
+        if (!ok) continue;
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
+        const int32_t pmin = (int32_t)d.pmin;
+        const uint32_t imin = (uint32_t)(int32_t)d.imin, pix = (uint32_t)jb.pixels;
+        const bool per = jb.periodic == 1;
+        const int redo = __any(tiny);                  // a quotient below the float32 normal range: IEEE division
+
+        // ---- re-base, pack, store: two pack tiles of 8,192 elements ----------------------------------
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t tbase = base + (int64_t)h * kTile;
+            if (tbase >= jb.n) break;
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < kV / 2; ++k) {
+                    u32x4 r;
+                    if (__builtin_expect(redo, 0)) {
+                        // a tiny quotient somewhere in this wave: redo this lane's own elements with the
+                        // IEEE division (the floats are reloaded: the registers hold indices by now)
+                        const f32x4 xv = ldg<f32x4>(x + tbase + 4 * (k * kThreads + tid));
+                        for (int c = 0; c < 4; ++c) e[h * (kV / 2) + k][c] = (uint32_t)(int32_t)quant_floor(xv[c], low, dx);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        uint32_t uq = e[h * (kV / 2) + k][c];
+                        if (per && (int32_t)uq < pmin) uq += pix;          // bound(), group.go:374-382
+                        r[c] = uq - imin;                                  // group.go:247
+                    }
+                    *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreads + tid))) = r;
+                }
+            } else {
+                for (int i = tid; i < kTile; i += kThreads) {
+                    uint32_t r = 0;
+                    if (tbase + i < jb.n) {
+                        const int32_t qq = (int32_t)quant_floor(ldg<float>(x + tbase + i), low, dx);
+                        uint32_t uq = (uint32_t)qq;
+                        if (per && qq < pmin) uq += pix;
+                        r = uq - imin;
+                    }
+                    lds[stage32_idx(i)] = r;
+                }
+            }
+            lds_barrier();
+            uint32_t g[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup / 4; ++k) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+                g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+            }
+            lds_barrier();
+            pack_group32(g, b, lds + tid * b);
+            lds_barrier();
+            const int64_t tile_byte0 = tbase / 8 * b;
+            int64_t tile_bytes = (int64_t)kTile / 8 * b;
+            if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+            store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+            lds_barrier();
         }
     }
 }
@@ -1224,6 +1422,15 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
     hipLaunchKernelGGL(k_encode_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, gtile, gjob, ngroups, stats, (JobSync*)sync, abort_flag, meta);
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
+void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, uint64_t* stats, void* sync,
+                           uint32_t* abort_flag, Meta* meta) {
+    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, items, stats, (JobSync*)sync, abort_flag, meta);
+}
+int encode_reg_f32_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32, kThreads, 0) != hipSuccess) return 0;
+    return n;
+}
 int encode_f32_blocks_per_cu() {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_f32, kThreads, 0) != hipSuccess) return 0;

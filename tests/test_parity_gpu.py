@@ -442,3 +442,38 @@ def test_c2_full_size_properties(mnw, ctx, oracle, torch_mod):
     q2 = torch.floor((y - low) / 0.001)
     frac_moved = float((q1 != q2).double().mean())
     assert frac_moved < 0.02
+
+
+# ------------------------------------------------------------------------------------------------
+# the opt-in encode structures must produce the same bytes as the default one
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fused", "single_read"])
+def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(21)
+    low, high, pixels = 0.0, 250.0, 250000
+    sizes = [1, 63, 8191, 8192, 8193, 16384, 16385, 40000, 100001, 300000, 2**20 + 17, 5 * 2**20]
+    xs = []
+    for k, n in enumerate(sizes):
+        c, sg = [(125.0, 20.0), (0.2, 0.4), (249.8, 0.5), (60.0, 0.01)][k % 4]
+        x = np.mod(c + sg * rng.standard_normal(n), 250.0).astype(np.float32)
+        x[x >= np.float32(250.0)] = 0.0        # exact zeros: quotient 0 must not take the slow path wrongly
+        xs.append(x)
+    xs.append(np.full(70000, 25.0, dtype=np.float32))                      # constant block: bits == 0
+    bad = np.mod(125 + 5 * rng.standard_normal(50000), 250).astype(np.float32); bad[777] = np.nan
+    xs.append(bad)                                                         # exact path inside a batch
+    with mnw.Context(0) as c2:
+        c2.set_option(mode, 1)
+        c2.set_option("group_bytes", 3 << 20)      # several groups for the fused form
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]   # the NaN block needs 64 bits
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
+                for t, o in zip(ts, outs)]
+        for rep in range(3):                        # slots are reused: stale sync words would show up here
+            metas = c2.encode_blocks(jobs)
+            torch.cuda.synchronize()
+            for x, m, o in zip(xs, metas, outs):
+                omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
+                assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+                assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()

@@ -13,6 +13,7 @@ p.add_argument("--blocks", type=str, default="22,24,26,27")
 p.add_argument("--grids", type=str, default="0")
 p.add_argument("--groups", type=str, default="0")
 p.add_argument("--fused", type=str, default="0")
+p.add_argument("--single", type=str, default="1")
 p.add_argument("--reps", type=int, default=10)
 a = p.parse_args()
 
@@ -26,7 +27,8 @@ ctx = mnw.Context(0)
 stream = None
 pixels = 250000
 
-def run(B, grid, group_mb, fused=0):
+def run(B, grid, group_mb, fused=0, single=1):
+    ctx.set_option("single_read", single)
     ctx.set_option("grid_cap", grid)
     ctx.set_option("group_bytes", group_mb << 20)
     ctx.set_option("fused", fused)
@@ -53,8 +55,8 @@ def run(B, grid, group_mb, fused=0):
     td = timeit(lambda: ctx.decode_blocks(dj, stream=stream))
     pb = sum(m.nbytes for m in metas)
     alg = 4.0 * N + pb
-    print("B=2^%-4.1f grid=%-5d group=%-4dMB fused=%d  enc best %.1f us avg %.1f us (%.2f TB/s alg)   dec best %.1f us avg %.1f (%.2f TB/s alg)" % (
-        __import__('math').log2(B), grid, group_mb, fused, te[0]*1e3, te[1]*1e3, alg/te[0]/1e9, td[0]*1e3, td[1]*1e3, alg/td[0]/1e9), flush=True)
+    print("B=2^%-4.1f grid=%-5d group=%-4dMB fused=%d single=%d  enc best %.1f us avg %.1f us (%.2f TB/s alg)   dec best %.1f us avg %.1f (%.2f TB/s alg)" % (
+        __import__('math').log2(B), grid, group_mb, fused, single, te[0]*1e3, te[1]*1e3, alg/te[0]/1e9, td[0]*1e3, td[1]*1e3, alg/td[0]/1e9), flush=True)
     print("      events:", ks, flush=True)
 
 for bl in a.blocks.split(","):
@@ -62,4 +64,5 @@ for bl in a.blocks.split(","):
     for gr in a.grids.split(","):
         for gp in a.groups.split(","):
             for fu in a.fused.split(","):
-                run(B, int(gr), int(gp), int(fu))
+                for si in a.single.split(","):
+                    run(B, int(gr), int(gp), int(fu), int(si))
