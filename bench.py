@@ -157,6 +157,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sync_all()      # the context has its own stream: the synthetic column must be complete first
     for _ in range(a.warmup):
         metas = step()
     sync_all()

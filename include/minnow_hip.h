@@ -43,7 +43,9 @@ extern "C" {
 #define MNW_FLOAT_GROUP  11
 
 typedef struct mnw_ctx mnw_ctx;       /* one per Writer/Reader; not thread-safe, like the reference */
-typedef void *mnw_stream_t;           /* a hipStream_t (NULL = the context's own stream) */
+typedef void *mnw_stream_t;           /* a hipStream_t; NULL = the context's own stream, a non-blocking stream
+                                         that is NOT ordered with the legacy default stream: buffers produced
+                                         on other streams must be complete before they are passed in */
 
 /* ---- context --------------------------------------------------------------------------- */
 int mnw_ctx_create(int device, mnw_ctx **ctx);

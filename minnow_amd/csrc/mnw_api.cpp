@@ -157,7 +157,10 @@ int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
         const size_t off_gtile = sizeof(DevJob) * cap;
         const size_t off_gjob = off_gtile + sizeof(int64_t) * (cap + 1);
         sl.up_bytes = (off_gjob + sizeof(int) * (cap + 2) + 15) / 16 * 16;
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_up, sl.up_bytes, hipHostMallocDefault));
+        // Coherent (fine-grained) pinned memory: the GPU reads the job table straight out of it in
+        // k_prepare and writes the metadata straight into it, batch after batch.  With the default
+        // (non-coherent) kind the GPU may keep lines of it cached across launches and copy a stale table.
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_up, sl.up_bytes, hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(c, hipMalloc((void**)&sl.d_up, sl.up_bytes));
         memset(sl.h_up, 0, sl.up_bytes);
         sl.h_jobs = (DevJob*)sl.h_up; sl.d_jobs = (DevJob*)sl.d_up;
@@ -167,8 +170,8 @@ int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
         const size_t stats_bytes = sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * cap;
         HIPCHK(c, hipMalloc((void**)&sl.d_stats, stats_bytes + sizeof(uint32_t) * kSyncPad + sl.sync_stride * cap));
         sl.d_sync = (uint8_t*)sl.d_stats + stats_bytes;
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void**)&sl.h_sync, sizeof(uint32_t) * kSyncPad, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_meta, sizeof(Meta) * cap, hipHostMallocCoherent | hipHostMallocMapped));
+        HIPCHK(c, hipHostMalloc((void**)&sl.h_sync, sizeof(uint32_t) * kSyncPad, hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer((void**)&sl.d_meta, sl.h_meta, 0));
         HIPCHK(c, hipHostGetDevicePointer((void**)&sl.d_hsync, sl.h_sync, 0));
         sl.cap = cap;

@@ -507,14 +507,17 @@ __device__ __forceinline__ void pack_group32(const uint32_t (&v)[kGroup], uint32
     }
 }
 
-// 33..64-bit values: each is the field pair (low 32 bits, high b-32 bits) of the same LSB-first stream
-__device__ __forceinline__ void pack_group64(const uint64_t (&v)[kGroup], uint32_t b, uint32_t* __restrict__ out) {
+// 33..64-bit values: each is the field pair (low 32 bits, high b-32 bits) of the same LSB-first stream.
+// Register-light form for the rare wide path: the lane's 32 values are read from LDS one at a time
+// (`in`, 8-byte aligned) and its b words go to a separate LDS region (`out`).
+__device__ __forceinline__ void pack_group64_lds(const uint32_t* __restrict__ in, uint32_t b, uint32_t* __restrict__ out) {
     uint32_t acc = 0;
     uint32_t pos = 0;
     const uint32_t bh = b - 32;                    // 1..32
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < kGroup; ++i) {
-        const uint32_t lo = (uint32_t)v[i], hi = (uint32_t)(v[i] >> 32);
+        const u32x2 w = *reinterpret_cast<const u32x2*>(in + 2 * i);
+        const uint32_t lo = w.x, hi = w.y;
         // low field, width 32: always completes a word
         acc |= lo << pos;
         *out++ = acc;
@@ -1021,11 +1024,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_reg_f32(const DevJob* __
 // pack pass, int64 blocks (intGroup.writeData, and raw bit.BufferedArray in explicit mode).
 // The width is only known on the device, so the kernel carries both the 32-bit and the 64-bit path.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict__ jobs, int njobs,
-                                                       int64_t total_tiles,
-                                                       const uint64_t* __restrict__ stats,
-                                                       Meta* __restrict__ meta) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds64 / 4];
+__global__ __launch_bounds__(kThreads, 4) void k_pack_i64(const DevJob* __restrict__ jobs, int njobs,
+                                                          int64_t total_tiles,
+                                                          const uint64_t* __restrict__ stats,
+                                                          Meta* __restrict__ meta) {
+    // One 36 KB LDS block for both widths (4 workgroups per CU): a stage of 8,192 32-bit values, or -- for
+    // widths above 32 -- a quarter tile of 64-bit values plus a separate output region.
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds32 / 4];
     constexpr int kV = kTile / (2 * kThreads);       // 16-byte loads per thread per tile (16)
     const int tid = threadIdx.x;
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
@@ -1037,6 +1042,7 @@ __global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict_
         const DevJob jb = jobs[j];
         const int64_t jend = jb.tile0 + tiles_of(jb.n);
         const int64_t tend = t1 < jend ? t1 : jend;
+        const int64_t* __restrict__ x = (const int64_t*)jb.src;
         uint64_t st[5] = {0, 0, 0, 0, 0};
         if (jb.mode == kModeStats) load_stats<false>(stats, j, st);
         const Desc d = make_desc_i64(jb, st);
@@ -1046,33 +1052,42 @@ __global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict_
         }
         const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
         if (ok) {
-            const int64_t* __restrict__ x = (const int64_t*)jb.src;
             const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
             const uint64_t imin = (uint64_t)d.imin;
             const uint64_t mask = b == 64 ? ~0ull : ((1ull << b) - 1);   // bit.go:104-107
-            const bool narrow = b <= 32;
-            for (int64_t t = tend - 1; t >= t0; --t) {
-                const int64_t base = (t - jb.tile0) * kTile;
-                if (base + kTile <= jb.n) {
-#pragma unroll 4
-                    for (int k = 0; k < kV; ++k) {
-                        const i64x2 v = ldg<i64x2>(x + base + 2 * (k * kThreads + tid));
-                        const uint64_t a = ((uint64_t)v.x - imin) & mask;
-                        const uint64_t c = ((uint64_t)v.y - imin) & mask;
-                        const int e = 2 * (k * kThreads + tid);
-                        if (narrow) { u32x2 r; r.x = (uint32_t)a; r.y = (uint32_t)c; *reinterpret_cast<u32x2*>(lds + stage32_idx(e)) = r; }
-                        else { u64x2 r; r.x = a; r.y = c; *reinterpret_cast<u64x2*>(lds + stage64_idx(e)) = r; }
-                    }
-                } else {
-                    for (int i = tid; i < kTile; i += kThreads) {
-                        uint64_t r = 0;
-                        if (base + i < jb.n) r = ((uint64_t)ldg<int64_t>(x + base + i) - imin) & mask;
-                        if (narrow) lds[stage32_idx(i)] = (uint32_t)r;
-                        else *reinterpret_cast<uint64_t*>(lds + stage64_idx(i)) = r;
-                    }
+            if (b <= 32) {
+                // the range is walked backwards, so only the first tile handled can be the block's
+                // ragged last one and every prefetched tile is full
+                int64_t t = tend - 1;
+                i64x2 v[kV];
+                bool cur_full = (t - jb.tile0) * kTile + kTile <= jb.n;
+                if (cur_full) {
+#pragma unroll
+                    for (int k = 0; k < kV; ++k) v[k] = ldg<i64x2>(x + (t - jb.tile0) * kTile + 2 * (k * kThreads + tid));
                 }
-                lds_barrier();
-                if (narrow) {
+                for (; t >= t0; --t) {
+                    const int64_t base = (t - jb.tile0) * kTile;
+                    if (cur_full) {
+#pragma unroll
+                        for (int k = 0; k < kV; ++k) {
+                            u32x2 r;
+                            r.x = (uint32_t)(((uint64_t)v[k].x - imin) & mask);      // group.go:247
+                            r.y = (uint32_t)(((uint64_t)v[k].y - imin) & mask);
+                            *reinterpret_cast<u32x2*>(lds + stage32_idx(2 * (k * kThreads + tid))) = r;
+                        }
+                    } else {
+                        for (int i = tid; i < kTile; i += kThreads) {
+                            uint64_t r = 0;
+                            if (base + i < jb.n) r = ((uint64_t)ldg<int64_t>(x + base + i) - imin) & mask;
+                            lds[stage32_idx(i)] = (uint32_t)r;
+                        }
+                    }
+                    if (t - 1 >= t0) {               // next tile's loads stay in flight across the barriers
+#pragma unroll
+                        for (int k = 0; k < kV; ++k) v[k] = ldg<i64x2>(x + base - kTile + 2 * (k * kThreads + tid));
+                    }
+                    cur_full = true;
+                    lds_barrier();
                     uint32_t g[kGroup];
 #pragma unroll
                     for (int k = 0; k < kGroup / 4; ++k) {
@@ -1081,22 +1096,40 @@ __global__ __launch_bounds__(kThreads) void k_pack_i64(const DevJob* __restrict_
                     }
                     lds_barrier();
                     pack_group32(g, b, lds + tid * b);
-                } else {
-                    uint64_t g[kGroup];
-#pragma unroll
-                    for (int k = 0; k < kGroup / 2; ++k) {
-                        const u64x2 r = *reinterpret_cast<const u64x2*>(lds + tid * kStride64 + 4 * k);
-                        g[2 * k] = r.x; g[2 * k + 1] = r.y;
-                    }
                     lds_barrier();
-                    pack_group64(g, b, lds + tid * b);
+                    const int64_t tile_byte0 = base / 8 * b;
+                    int64_t tile_bytes = (int64_t)kTile / 8 * b;
+                    if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+                    store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                    lds_barrier();
                 }
-                lds_barrier();
-                const int64_t tile_byte0 = base / 8 * b;
-                int64_t tile_bytes = (int64_t)kTile / 8 * b;
-                if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
-                lds_barrier();
+            } else {
+                // widths above 32 (rare): a quarter tile of 64-bit values at a time; lanes 0..63 pack one
+                // 32-element group each out of the stage into a separate output region of the same LDS
+                constexpr int kQ = kTile / 4;                       // 2,048 elements = 64 groups
+                constexpr int kOut = (kQ / kGroup) * kStride64;     // output region starts after the stage (dwords)
+                static_assert((kOut + (kQ / kGroup) * 64) * 4 <= kLds32, "wide stage + output fit");
+                for (int64_t t = tend - 1; t >= t0; --t) {
+                    const int64_t base = (t - jb.tile0) * kTile;
+                    for (int h = 0; h < 4; ++h) {
+                        const int64_t hbase = base + (int64_t)h * kQ;
+                        if (hbase >= jb.n) break;
+                        for (int i = 2 * tid; i < kQ; i += 2 * kThreads) {
+                            u64x2 r;
+                            r.x = hbase + i < jb.n ? (((uint64_t)ldg<int64_t>(x + hbase + i) - imin) & mask) : 0;
+                            r.y = hbase + i + 1 < jb.n ? (((uint64_t)ldg<int64_t>(x + hbase + i + 1) - imin) & mask) : 0;
+                            *reinterpret_cast<u64x2*>(lds + stage64_idx(i)) = r;
+                        }
+                        lds_barrier();
+                        if (tid < kQ / kGroup) pack_group64_lds(lds + tid * kStride64, b, lds + kOut + tid * b);
+                        lds_barrier();
+                        const int64_t tile_byte0 = hbase / 8 * b;
+                        int64_t tile_bytes = (int64_t)kQ / 8 * b;
+                        if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+                        store_tile(lds + kOut, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                        lds_barrier();
+                    }
+                }
             }
         }
         t0 = tend;
@@ -1232,8 +1265,12 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
                         }
                         qd = (double)q;
                     }
+#ifdef MNW_DIAG_NO_DITHER      // diagnostic builds only (tools/microbench): price the dither
+                    const double u = 0.0; (void)ka; (void)kb;
+#else
                     const uint32_t z = dither_bits((uint32_t)(base + i), ka, kb);
                     const double u = (double)z * (1.0 / 4294967296.0);
+#endif
                     // group.go:308: dx*float32(float64(q) + u) + low, float32 multiply then add
                     r[c] = __fadd_rn(__fmul_rn(dx, (float)__dadd_rn(qd, u)), low);
                 }

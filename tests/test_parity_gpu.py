@@ -327,6 +327,7 @@ def test_batched_mixed_blocks_device_api(mnw, ctx, oracle, torch_mod):
             o = torch.zeros(8 * n + 16, dtype=torch.uint8, device=dev)
             jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), n, o.numel(), mnw.INT_GROUP))
         host_in.append(x); outs.append(o); keep.append(t)
+    torch.cuda.synchronize()      # inputs/outputs were produced on torch's stream
     metas = ctx.encode_blocks(jobs, stream=stream)
     torch.cuda.synchronize()
     # one contiguous "file image" with byte-granular offsets, as blockIndex lays blocks out
@@ -354,6 +355,7 @@ def test_batched_mixed_blocks_device_api(mnw, ctx, oracle, torch_mod):
             o = torch.empty(n, dtype=torch.int64, device=dev)
             djobs.append(mnw.DecJob(img.data_ptr() + offs[k], o.data_ptr(), n, m.nbytes, m.min, m.bits, mnw.INT_GROUP))
         douts.append(o)
+    torch.cuda.synchronize()
     ctx.decode_blocks(djobs, stream=stream)
     torch.cuda.synchronize()
     for k, (x, m, o) in enumerate(zip(host_in, metas, douts)):
@@ -372,6 +374,7 @@ def test_capacity_error_reported_per_block(mnw, ctx, torch_mod):
     dev = torch.device("cuda:0")
     x = torch.arange(0, 100000, dtype=torch.int64, device=dev)
     o = torch.zeros(64, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     metas = ctx.encode_blocks([mnw.EncJob(x.data_ptr(), o.data_ptr(), x.numel(), 64, mnw.INT_GROUP)], check=False)
     assert metas[0].status == -5 and metas[0].bits == 17
     assert int(o.sum().item()) == 0                                # nothing written
@@ -386,6 +389,7 @@ def test_async_split_form(mnw, ctx, oracle, torch_mod):
     os_ = [torch.zeros(4 * x.size, dtype=torch.uint8, device=dev) for x in xs]
     jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, 0.0, 250.0, 250000, 1)
             for t, o in zip(ts, os_)]
+    torch.cuda.synchronize()
     ctx.encode_blocks_async(jobs)
     with pytest.raises(mnw.MnwError):
         ctx.encode_blocks_async(jobs)            # one batch at a time (block order == file order)
@@ -415,6 +419,7 @@ def test_c2_full_size_properties(mnw, ctx, oracle, torch_mod):
     outs = [torch.zeros(4 * min(B, N - k * B), dtype=torch.uint8, device=dev) for k in range(nblk)]
     jobs = [mnw.EncJob(x.data_ptr() + 4 * k * B, outs[k].data_ptr(), min(B, N - k * B), outs[k].numel(),
                        mnw.FLOAT_GROUP, low, high, pixels, 1) for k in range(nblk)]
+    torch.cuda.synchronize()
     metas = ctx.encode_blocks(jobs)
     torch.cuda.synchronize()
     assert all(m.status == 0 for m in metas)
@@ -431,6 +436,7 @@ def test_c2_full_size_properties(mnw, ctx, oracle, torch_mod):
     y = torch.empty_like(x)
     djobs = [mnw.DecJob(outs[k].data_ptr(), y.data_ptr() + 4 * k * B, jobs[k].n, metas[k].nbytes, metas[k].min,
                         metas[k].bits, mnw.FLOAT_GROUP, low, high, pixels, 1, seed=1, block=k) for k in range(nblk)]
+    torch.cuda.synchronize()
     ctx.decode_blocks(djobs)
     torch.cuda.synchronize()
     d = (y.double() - x.double()).abs()
@@ -470,6 +476,7 @@ def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
         outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]   # the NaN block needs 64 bits
         jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
                 for t, o in zip(ts, outs)]
+        torch.cuda.synchronize()
         for rep in range(3):                        # slots are reused: stale sync words would show up here
             metas = c2.encode_blocks(jobs)
             torch.cuda.synchronize()

@@ -36,6 +36,7 @@ def run(B, grid, group_mb, fused=0, single=1):
     slot = (4 * B + 15) // 16 * 16
     packed = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
     ej = [mnw.EncJob(x.data_ptr() + 4*k*B, packed.data_ptr() + k*slot, min(B, N-k*B), slot, mnw.FLOAT_GROUP, 0.0, 250.0, pixels, 1) for k in range(nblk)]
+    torch.cuda.synchronize()
     metas = ctx.encode_blocks(ej, stream=stream)
     dj = [mnw.DecJob(packed.data_ptr() + k*slot, y.data_ptr() + 4*k*B, ej[k].n, metas[k].nbytes, metas[k].min, metas[k].bits, mnw.FLOAT_GROUP, 0.0, 250.0, pixels, 1, 1, k) for k in range(nblk)]
     def timeit(fn):
