@@ -75,6 +75,9 @@ int mnw_pack_u64(mnw_ctx *ctx, const uint64_t *x, int64_t n, int bits, uint8_t *
 /* (*bit.Array).Slice(out), bit.go:29-82.  in_len must be >= ArrayBytes(bits, n). */
 int mnw_unpack_u64(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int bits, int64_t n, uint64_t *out);
 
+/* bit.ArrayBuffer.Bits(x), bit.go:151-159: PrecisionNeeded(max(x)); 0 when x is empty. */
+int mnw_bits_u64(mnw_ctx *ctx, const uint64_t *x, int64_t n, int64_t *bits);
+
 /* intGroup.writeData, group.go:242-250: min, buf = x-min, bits = Bits(buf), pack.
  * *out_len = ArrayBytes(bits, n), 0 when bits == 0 (bit.go:162).  cap = capacity of out. */
 int mnw_int_encode(mnw_ctx *ctx, const int64_t *x, int64_t n, int64_t *min, int64_t *bits,

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mnw_float_group_pixels": (_i64, [_f32, _f32, _f32]),
     "mnw_pack_u64": (_int, [_p, _p, _i64, _int, _p, _i64]),
     "mnw_unpack_u64": (_int, [_p, _p, _i64, _int, _i64, _p]),
+    "mnw_bits_u64": (_int, [_p, _p, _i64, C.POINTER(_i64)]),
     "mnw_int_encode": (_int, [_p, _p, _i64, C.POINTER(_i64), C.POINTER(_i64), _p, _i64, C.POINTER(_i64)]),
     "mnw_int_decode": (_int, [_p, _p, _i64, _i64, _i64, _i64, _p]),
     "mnw_float_encode": (_int, [_p, _p, _i64, _f32, _f32, _i64, _int, C.POINTER(_i64), C.POINTER(_i64),

@@ -853,6 +853,38 @@ int mnw_pack_u64(mnw_ctx* c, const uint64_t* x, int64_t n, int bits, uint8_t* ou
     return MNW_OK;
 }
 
+// bit.ArrayBuffer.Bits (bit.go:151-159): PrecisionNeeded(max(x)), 0 when x is empty.  The max scan runs
+// on the GPU (k_reduce_i64 in unsigned mode).
+int mnw_bits_u64(mnw_ctx* c, const uint64_t* x, int64_t n, int64_t* bits) {
+    if (!c) return MNW_E_ARG;
+    if (n < 0 || !bits) return fail(c, MNW_E_ARG, "bits: bad arguments");
+    *bits = 0;
+    if (n == 0) return MNW_OK;
+    if (!x) return fail(c, MNW_E_ARG, "bits: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = stage_in(c, x, (size_t)n * 8);
+    if (rc) return rc;
+    JobSlot* sl;
+    rc = acquire_slot(c, 1, &sl);
+    if (rc) return rc;
+    DevJob& d = sl->h_jobs[0];
+    memset(&d, 0, sizeof d);
+    d.src = c->d_in; d.n = n; d.kind = MNW_INT_GROUP; d.mode = mnw::kModeUnsigned; d.tile0 = 0;
+    rc = prepare_slot(c, sl, c->stream, 1, true);
+    if (rc) return rc;
+    const int64_t tiles = (n + mnw::kTile - 1) / mnw::kTile;
+    { ScopedTimer t(c, c->stream, MNW_K_REDUCE_I64); mnw::launch_reduce_i64(c->stream, grid_for(c, tiles), sl->d_jobs, 1, tiles, sl->d_stats); }
+    HIPCHK(c, hipGetLastError());
+    uint64_t st[mnw::kStatSlots * mnw::kStatWords];
+    HIPCHK(c, hipMemcpyAsync(st, sl->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t mx = 0;
+    for (int k = 0; k < mnw::kStatSlots; ++k) if (st[k * mnw::kStatWords] > mx) mx = st[k * mnw::kStatWords];
+    // stat word 0 = bias(max of x ^ signbit) = the unsigned max itself
+    *bits = mnw_precision_needed(mx);
+    return MNW_OK;
+}
+
 int mnw_unpack_u64(mnw_ctx* c, const uint8_t* in, int64_t in_len, int bits, int64_t n, uint64_t* out) {
     if (!c) return MNW_E_ARG;
     if (n < 0 || bits < 0 || bits > 64 || in_len < 0) return fail(c, MNW_E_ARG, "unpack: bad arguments");

@@ -41,6 +41,7 @@ struct DevJob {
 
 constexpr int kModeStats = 0;
 constexpr int kModeExplicit = 1;
+constexpr int kModeUnsigned = 2;   // reduce only: the int64 input holds uint64 values
 
 // per-block result, same layout as mnw_block_meta
 struct Meta {

@@ -413,6 +413,9 @@ __global__ __launch_bounds__(kThreads, 8) void k_reduce_i64(const DevJob* __rest
         const int64_t tend = t1 < jend ? t1 : jend;
         const int64_t* __restrict__ x = (const int64_t*)jb.src;
         int64_t mn = INT64_MAX, mx = INT64_MIN;
+        // kModeUnsigned (bit.ArrayBuffer.Bits on raw uint64 values, bit.go:151-159): flipping the sign
+        // bit maps unsigned order onto signed order
+        const int64_t flip = (jb.mode == kModeUnsigned) ? INT64_MIN : 0;
 
         int64_t c = (t0 - jb.tile0) * kTile;
         int64_t e1 = (tend - jb.tile0) * kTile;
@@ -423,12 +426,13 @@ __global__ __launch_bounds__(kThreads, 8) void k_reduce_i64(const DevJob* __rest
             for (int k = 0; k < 4; ++k) va[k] = ldg<i64x2>(x + c + 2 * (k * kThreads + tid));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                mn = va[k].x < mn ? va[k].x : mn; mx = va[k].x > mx ? va[k].x : mx;
-                mn = va[k].y < mn ? va[k].y : mn; mx = va[k].y > mx ? va[k].y : mx;
+                const int64_t p = va[k].x ^ flip, q = va[k].y ^ flip;
+                mn = p < mn ? p : mn; mx = p > mx ? p : mx;
+                mn = q < mn ? q : mn; mx = q > mx ? q : mx;
             }
         }
         for (int64_t i = c + tid; i < e1; i += kThreads) {
-            const int64_t v = ldg<int64_t>(x + i);
+            const int64_t v = ldg<int64_t>(x + i) ^ flip;
             mn = v < mn ? v : mn; mx = v > mx ? v : mx;
         }
         mn = wave_min_i64(mn);
