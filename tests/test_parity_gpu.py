@@ -484,3 +484,116 @@ def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
                 omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
                 assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
                 assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 3 and 4 at reduced row counts (parity-test cases, not bench lines)
+# ------------------------------------------------------------------------------------------------
+def test_c3_mixed_halo_catalogue_columns(mnw, ctx, oracle, torch_mod):
+    """SURVEY 8d C3 shape: 32 mixed columns (3 position, 3 velocity, 18 log/linear float, 4 int,
+    the 4 fixed-size ones are raw copies and not codec work) x 1e5 rows, one batch per block of rows,
+    exactly how minh.Writer.Block walks its columns (go/minh/minh.go:115-137)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    rows = 100000
+    cols = []
+    for c in range(3):
+        cols.append(("f", np.mod(125 + 20 * rng.standard_normal(rows), 250).astype(np.float32), (0.0, 250.0, 0.001)))
+    for c in range(3):
+        v = np.clip(300 * rng.standard_normal(rows), -4999, 4999).astype(np.float32)
+        cols.append(("f", v, (-5000.0, 5000.0, 1.0)))
+    for c in range(18):
+        v = np.clip(10 + c * 0.2 + 0.8 * rng.standard_normal(rows), 8.001, 15.99).astype(np.float32)
+        cols.append(("f", v, (8.0, 16.0, 0.01)))
+    cols.append(("i", (5 * 10**9 + np.arange(rows)).astype(np.int64), None))
+    cols.append(("i", rng.poisson(40, rows).astype(np.int64), None))
+    cols.append(("i", rng.integers(-1, 2**20, rows).astype(np.int64), None))
+    cols.append(("i", np.full(rows, 7, dtype=np.int64), None))
+    jobs, outs, keep, params = [], [], [], []
+    for kind, v, lim in cols:
+        t = torch.from_numpy(v).to(dev)
+        o = torch.zeros(8 * rows + 16, dtype=torch.uint8, device=dev)
+        if kind == "f":
+            low, high, dx = lim
+            pixels = mnw.float_group_pixels(low, high, dx)
+            assert pixels == oracle.float_group_pixels(low, high, dx)
+            jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), rows, o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1))
+            params.append((low, high, pixels))
+        else:
+            jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), rows, o.numel(), mnw.INT_GROUP))
+            params.append(None)
+        outs.append(o); keep.append(t)
+    torch.cuda.synchronize()
+    metas = ctx.encode_blocks(jobs)
+    torch.cuda.synchronize()
+    djobs, douts = [], []
+    for k, ((kind, v, lim), m, o, pr) in enumerate(zip(cols, metas, outs, params)):
+        if kind == "f":
+            omin, obits, odata = oracle.float_encode(v, pr[0], pr[1], pr[2], True, literal=False)
+            y = torch.empty(rows, dtype=torch.float32, device=dev)
+            djobs.append(mnw.DecJob(o.data_ptr(), y.data_ptr(), rows, m.nbytes, m.min, m.bits, mnw.FLOAT_GROUP, pr[0], pr[1], pr[2], 1, 3, k))
+        else:
+            omin, obits, odata = oracle.int_encode(v, literal=False)
+            y = torch.empty(rows, dtype=torch.int64, device=dev)
+            djobs.append(mnw.DecJob(o.data_ptr(), y.data_ptr(), rows, m.nbytes, m.min, m.bits, mnw.INT_GROUP))
+        assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), k
+        assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), k
+        douts.append(y)
+    torch.cuda.synchronize()
+    ctx.decode_blocks(djobs)
+    torch.cuda.synchronize()
+    for (kind, v, lim), y in zip(cols, douts):
+        got = y.cpu().numpy()
+        if kind == "f":
+            assert np.all(np.abs(got.astype(np.float64) - v.astype(np.float64)) <= lim[2] * 1.01 + 1e-3)
+        else:
+            assert np.array_equal(got, v)
+
+
+def test_c4_particle_snapshot_blocks(mnw, ctx, oracle, torch_mod):
+    """SURVEY 8d C4 shape, scaled: (x,y,z) Lagrangian grid + displacement wrapped into [0,250), periodic,
+    and (vx,vy,vz) non-periodic with data-derived limits (go/minp/minp.go:87-96), 27 sub-cell blocks of
+    64^3 particles per component -- one minnow group of many blocks per component (minp.go:112-118)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(41)
+    nsub, nblk = 64**3, 27
+    jobs, outs, keep, spec = [], [], [], []
+    for comp in range(6):
+        for b in range(nblk):
+            if comp < 3:
+                grid = (np.arange(nsub) % 64) * (250.0 / 192) + (b % 3) * (250.0 / 3)
+                v = np.mod(grid + 2 * rng.standard_normal(nsub), 250.0).astype(np.float32)
+                v[v >= np.float32(250.0)] = 0.0
+                low, high, pixels, per = 0.0, 250.0, 250000, 1
+            else:
+                v = (300 * rng.standard_normal(nsub)).astype(np.float32)
+                low, high = float(v.min()), float(np.nextafter(v.max(), np.float32(np.inf)))
+                pixels, per = mnw.float_group_pixels(low, high, 1.0), 0
+            t = torch.from_numpy(v).to(dev)
+            o = torch.zeros(4 * nsub + 16, dtype=torch.uint8, device=dev)
+            jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), nsub, o.numel(), mnw.FLOAT_GROUP, low, high, pixels, per))
+            outs.append(o); keep.append(t); spec.append((v, low, high, pixels, per))
+    torch.cuda.synchronize()
+    metas = ctx.encode_blocks(jobs)
+    torch.cuda.synchronize()
+    for k in range(0, len(jobs), 7):           # every 7th block against the oracle, byte for byte
+        v, low, high, pixels, per = spec[k]
+        omin, obits, odata = oracle.float_encode(v, low, high, pixels, bool(per), literal=False)
+        m = metas[k]
+        assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), k
+        assert outs[k][: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), k
+    ys = [torch.empty(nsub, dtype=torch.float32, device=dev) for _ in jobs]
+    djobs = [mnw.DecJob(outs[k].data_ptr(), ys[k].data_ptr(), nsub, metas[k].nbytes, metas[k].min, metas[k].bits,
+                        mnw.FLOAT_GROUP, spec[k][1], spec[k][2], spec[k][3], spec[k][4], 9, k) for k in range(len(jobs))]
+    torch.cuda.synchronize()
+    ctx.decode_blocks(djobs)
+    torch.cuda.synchronize()
+    for k in range(len(jobs)):
+        v, low, high, pixels, per = spec[k]
+        dxq = (np.float32(high) - np.float32(low)) / np.float32(pixels)
+        d = np.abs(ys[k].cpu().numpy().astype(np.float64) - v.astype(np.float64))
+        if per:
+            d = np.minimum(d, 250.0 - d)
+        assert d.max() <= float(dxq) * 1.01 + 1e-3, (k, d.max())
