@@ -97,24 +97,48 @@ class Context:
     # -- batched device-pointer API -----------------------------------------------------------
     @staticmethod
     def _enc_array(jobs):
+        """EncJob list -> C array.  A caller that encodes the same batch repeatedly can build the array
+        once with `enc_batch()` and pass that instead of the list."""
+        if isinstance(jobs, C.Array):
+            return jobs
         arr = (EncJobC * max(len(jobs), 1))()
         for i, j in enumerate(jobs):
             arr[i] = EncJobC(j.src, j.dst, j.n, j.cap, j.pixels, j.low, j.high, j.kind, j.periodic)
+        arr._n = len(jobs)
         return arr
+
+    enc_batch = _enc_array
+
+    @staticmethod
+    def dec_batch(jobs):
+        if isinstance(jobs, C.Array):
+            return jobs
+        arr = (DecJobC * max(len(jobs), 1))()
+        for i, j in enumerate(jobs):
+            arr[i] = DecJobC(j.src, j.dst, j.n, j.src_len, j.min, j.bits, j.pixels, j.low, j.high,
+                             j.kind, j.periodic, j.seed, j.block)
+        arr._n = len(jobs)
+        return arr
+
+    @staticmethod
+    def _count(jobs):
+        return jobs._n if isinstance(jobs, C.Array) else len(jobs)
 
     def encode_blocks(self, jobs, stream=None, check=True):
         arr = self._enc_array(jobs)
-        meta = (BlockMetaC * max(len(jobs), 1))()
-        rc = self._L.mnw_encode_blocks(self._h, stream, arr, len(jobs), meta)
-        out = [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[: len(jobs)]]
+        n = self._count(arr)
+        meta = (BlockMetaC * max(n, 1))()
+        rc = self._L.mnw_encode_blocks(self._h, stream, arr, n, meta)
+        out = [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[:n]]
         if check:
             self._check(rc)
         return out
 
     def encode_blocks_async(self, jobs, stream=None):
         arr = self._enc_array(jobs)
-        self._check(self._L.mnw_encode_blocks_async(self._h, stream, arr, len(jobs)))
-        self._pending_n = len(jobs)
+        n = self._count(arr)
+        self._check(self._L.mnw_encode_blocks_async(self._h, stream, arr, n))
+        self._pending_n = n
 
     def encode_blocks_finish(self, stream=None, check=True):
         n = self._pending_n
@@ -125,11 +149,8 @@ class Context:
         return [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[:n]]
 
     def decode_blocks(self, jobs, stream=None):
-        arr = (DecJobC * max(len(jobs), 1))()
-        for i, j in enumerate(jobs):
-            arr[i] = DecJobC(j.src, j.dst, j.n, j.src_len, j.min, j.bits, j.pixels, j.low, j.high,
-                             j.kind, j.periodic, j.seed, j.block)
-        self._check(self._L.mnw_decode_blocks(self._h, stream, arr, len(jobs)))
+        arr = self.dec_batch(jobs)
+        self._check(self._L.mnw_decode_blocks(self._h, stream, arr, self._count(arr)))
 
     def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
         self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))

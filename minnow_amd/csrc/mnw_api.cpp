@@ -20,7 +20,9 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*, void*, uint32_t*, Meta*);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, Meta*);
+size_t item_rec_bytes();
+int reg_max_items_per_block();
 int encode_reg_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
@@ -105,6 +107,12 @@ struct mnw_ctx {
     int single_read = 0;         // float encode through k_encode_reg_f32 (block read once): opt-in, see DESIGN.md
     int reg_blocks_per_cu = 0;   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
+    void* d_recs = nullptr;      // single read: one published statistics record per item (grow-only)
+    size_t cap_recs = 0;
+    uint32_t reg_gen = 0;        // generation tag of the records of the current batch (never 0)
+    int* h_itemjob = nullptr;    // single read: job of every item (pinned, coherent) and its device copy
+    int* d_itemjob = nullptr;
+    size_t cap_itemjob = 0;
     int fused_blocks_per_cu = 0; // co-resident workgroups of k_encode_f32 per CU (occupancy query)
     int64_t fused_aborts = 0;    // fused launches that fell back to the two-kernel path
     int pend_nfloat = 0;         // device slots [0, pend_nfloat) of the pending batch are float jobs
@@ -293,9 +301,17 @@ void fill_enc(DevJob& d, const mnw_enc_job& j) {
     d.low = j.low; d.high = j.high; d.kind = j.kind; d.periodic = j.periodic;
     d.mode = mnw::kModeStats;
     if (j.kind == MNW_FLOAT_GROUP) {
-        d.dxq = quant_dx(j.low, j.high, j.pixels);
-        d.rdx = 1.0 / (double)d.dxq;
-        d.xh = split_point(j.low, d.dxq, j.pixels / 2);
+        // the blocks of one group share (low, high, pixels): derive dx, 1/dx and the split point once
+        // per run of equal parameters (the bisection is ~64 float divisions)
+        static thread_local struct { float low, high; int64_t pixels; float dxq, xh; double rdx; bool valid; } memo = {0, 0, 0, 0, 0, 0, false};
+        if (!memo.valid || memcmp(&memo.low, &j.low, 4) || memcmp(&memo.high, &j.high, 4) || memo.pixels != j.pixels) {
+            memo.low = j.low; memo.high = j.high; memo.pixels = j.pixels;
+            memo.dxq = quant_dx(j.low, j.high, j.pixels);
+            memo.rdx = 1.0 / (double)memo.dxq;
+            memo.xh = split_point(j.low, memo.dxq, j.pixels / 2);
+            memo.valid = true;
+        }
+        d.dxq = memo.dxq; d.rdx = memo.rdx; d.xh = memo.xh;
     }
 }
 
@@ -375,25 +391,54 @@ int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int 
 int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
     if (c->reg_blocks_per_cu == 0) {
         int occ = mnw::encode_reg_f32_blocks_per_cu();
-        c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);
+        c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 2 ? 2 : occ);     // 512-thread workgroups, 72 KB LDS: two per CU
     }
     if (c->reg_blocks_per_cu < 1) return 1;
     int grid = c->cus * c->reg_blocks_per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
+    const int max_items = grid < mnw::reg_max_items_per_block() ? grid : mnw::reg_max_items_per_block();
     const int64_t item = 2 * mnw::kTile;
     int64_t items = 0;
     for (int k = 0; k < nfloat; ++k) {
         const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
-        if (ni > grid) return 1;
+        if (ni > max_items) return 1;
         sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
         items += ni;
     }
+    const size_t need = (size_t)items * mnw::item_rec_bytes();
+    if (need > c->cap_recs) {
+        // (re)allocation happens between batches only: the previous batch has been finished by then
+        if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
+        c->d_recs = nullptr; c->cap_recs = 0;
+        const size_t want = need + need / 2 + 4096;
+        HIPCHK(c, hipMalloc(&c->d_recs, want));
+        HIPCHK(c, hipMemsetAsync(c->d_recs, 0, want, s));      // tags of a fresh buffer must not match any generation
+        c->cap_recs = want;
+    }
+    if ((size_t)items > c->cap_itemjob) {
+        if (c->d_itemjob) { HIPCHK(c, hipStreamSynchronize(s)); hipFree(c->d_itemjob); hipHostFree(c->h_itemjob); }
+        c->d_itemjob = nullptr; c->h_itemjob = nullptr; c->cap_itemjob = 0;
+        const size_t want = (size_t)items + (size_t)items / 2 + 1024;
+        HIPCHK(c, hipMalloc((void**)&c->d_itemjob, want * sizeof(int)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_itemjob, want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+        c->cap_itemjob = want;
+    } else if (c->d_itemjob) {
+        // the table of the previous single-read batch may still be read by the copy kernel below
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    for (int k = 0; k < nfloat; ++k) {
+        const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
+        for (int64_t i = 0; i < ni; ++i) c->h_itemjob[i0 + i] = k;
+    }
+    if (items > 0) mnw::launch_prepare(s, c->h_itemjob, c->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16, nullptr, 0, nullptr, 0);
+    c->reg_gen = (c->reg_gen + 1) & 0x7fffffffu;
+    if (c->reg_gen == 0) c->reg_gen = 1;
     int rc = prepare_slot(c, sl, s, nslot_all, true);
     if (rc) return rc;
     if (items > 0) {
         if (items < grid) grid = (int)items;
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
-        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_stats, sync_ptr(sl, 0), abort_ptr(sl), sl->d_meta);
+        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, c->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_meta);
     }
     HIPCHK(c, hipGetLastError());
     mnw::launch_prepare(s, abort_ptr(sl), sl->d_hsync, 4, nullptr, 0, nullptr, 0);   // abort flag -> pinned host word
@@ -528,6 +573,8 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_out) hipFree(c->d_out);
     if (c->d_q) hipFree(c->d_q);
     if (c->d_state) hipFree(c->d_state);
+    if (c->d_recs) hipFree(c->d_recs);
+    if (c->d_itemjob) { hipFree(c->d_itemjob); hipHostFree(c->h_itemjob); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return MNW_OK;

@@ -539,10 +539,11 @@ __device__ __forceinline__ void pack_group64_lds(const uint32_t* __restrict__ in
 
 // coalesced write-out of one tile's packed words from LDS: 16-byte chunks, then the ragged tail of
 // the block's last tile byte-wise (ArrayBytes is a byte count, bit.go:23-25; pad bits are zero)
+template <int NT = kThreads>
 __device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out, uint8_t* __restrict__ dst,
                                            int64_t tile_byte0, int64_t tile_bytes) {
     const int full = (int)(tile_bytes >> 4);
-    for (int c = threadIdx.x; c < full; c += kThreads)
+    for (int c = threadIdx.x; c < full; c += NT)
         stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(lds_out + 4 * c));
     const int rem = (int)(tile_bytes & 15);
     if ((int)threadIdx.x < rem) {
@@ -841,24 +842,33 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 //
 // An item = 16,384 consecutive elements of one block = 64 values per lane, which stay in registers
 // from the load to the pack.  Workgroup w takes items w, w+G, w+2G, ... of the batch-wide item
-// numbering.  Per item: load -> fold the raw floats into the block's statistics (as k_reduce_f32) ->
-// count the item in -> [the workgroup whose count completes the block publishes its descriptor word]
-// -> wait for that word -> re-base, pack and store from the registers (two 8,192-element pack tiles).
-// While wave 0 runs the count-in round trips the other waves already turn their floats into pixel
-// indices (the float64 multiply, floor and convert need nothing from the descriptor).
+// numbering.  Per item: load -> fold the raw floats into the item's four statistics (as k_reduce_f32)
+// -> PUBLISH them as one 32-byte record of four self-validating 8-byte words {value, tag} (tag = this
+// batch's generation; one sc1 store each, no atomics, nothing to zero) -> wave 0 sweeps the records of
+// all items of the block until every tag is present and derives the block's descriptor itself (every
+// workgroup of the block computes the same descriptor; no counter, no "last arrival", one memory hop)
+// -> re-base, pack and store from the registers (one 16,384-element pack tile, 512 lanes x 32).  While wave 0 sweeps,
+// the other waves already turn their floats into pixel indices (the float64 multiply, floor and convert
+// need nothing from the descriptor).  This is the all-gather of tagged granules of
+// MI355X_MICROARCH.md ("allgather", "Valid forms": R2's granule needs no ordering).
 //
 // No deadlock if every block has at most G items and all G workgroups are resident: let m be the
 // smallest item any workgroup is blocked on.  Every item k of m's block is either < m (its owner has
-// moved past it, so it was counted in) or in (m, m+G): its owner handles items congruent to k mod G in
-// increasing order and is blocked on an item >= m, which can only be k itself or a later one -- and a
-// workgroup counts an item in BEFORE it waits for that item's block.  So the block is complete and its
-// last arrival has published the descriptor.  The host only sends blocks of at most G items here
-// (G x 16,384 = 2^24 elements at 4 workgroups per CU) and sizes G from the occupancy query; spins are
-// bounded and a timeout aborts the launch (the host then reruns the batch through the two-kernel path).
+// moved past it, so its record is published) or in (m, m+G): its owner handles items congruent to k mod G
+// in increasing order and is blocked on an item >= m, which can only be k itself or a later one -- and a
+// workgroup publishes an item's record BEFORE it waits for that item's block.  The host only sends
+// blocks of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; spins are bounded
+// and a timeout aborts the launch (the host then reruns the batch through the two-kernel path).
 // HBM traffic = algorithmic bytes: 4 B/element read + b/8 B/element written.
 // ------------------------------------------------------------------------------------------------
 constexpr int kItem = 2 * kTile;
+constexpr int kMaxSweep = 256;                      // items per block the sweep handles (2^22 elements)
 __device__ __forceinline__ int64_t items_of(int64_t n) { return (n + kItem - 1) / kItem; }
+
+struct ItemRec {                                     // 32 bytes: four {value: low 32, tag: high 32} words
+    uint64_t g[4];
+};
+constexpr uint32_t kRecBad = 0x80000000u;            // tag bit 31: the item held a NaN / infinity
 
 // job of item t (DevJob.tile0 holds the job's first ITEM in this launch's numbering)
 __device__ __forceinline__ int find_job_item(const DevJob* jobs, int lo, int njobs, int64_t t) {
@@ -870,42 +880,134 @@ __device__ __forceinline__ int find_job_item(const DevJob* jobs, int lo, int njo
     return lo;
 }
 
-__global__ __launch_bounds__(kThreads, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
-                                                             int64_t total_items, uint64_t* __restrict__ stats,
-                                                             JobSync* __restrict__ sync, uint32_t* __restrict__ abort_flag,
-                                                             Meta* __restrict__ meta) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLds32 / 4];
-    __shared__ float red[4][kThreads / 64];
-    __shared__ int redbad[kThreads / 64];
-    __shared__ uint64_t shared_slot;
-    constexpr int kV = kItem / (4 * kThreads);         // 16-byte loads per lane per item (16)
-    const int tid = threadIdx.x;
-    const int slot = blockIdx.x % kStatSlots;
-    int j = 0;
+// wave 0 only (not inlined: its float64 temporaries must not be live beside the 64 data registers).
+// Sweeps the block's records until all are present, then returns the descriptor word (0 on abort).
+__device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __restrict__ jobs, int j,
+                                                              const ItemRec* __restrict__ recs, uint32_t gen,
+                                                              uint32_t* __restrict__ abort_flag, Meta* __restrict__ meta,
+                                                              bool write_meta) {
+    const DevJob jb = jobs[j];
+    const int nitems = (int)items_of(jb.n);
+    const ItemRec* r0 = recs + jb.tile0;
+    uint64_t st[5];
+    uint32_t spins = 0;
+    for (;;) {
+        uint32_t v[4] = {0, 0, 0, 0};
+        uint32_t bad = 0, missing = 0;
+        for (int r = lane_id(); r < nitems; r += 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t w = __hip_atomic_load(&r0[r].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t tag = (uint32_t)(w >> 32);
+                missing |= (tag & ~kRecBad) != gen;
+                bad |= tag & kRecBad;
+                const uint32_t val = (uint32_t)w;
+                v[k] = val > v[k] ? val : v[k];
+            }
+        }
+        if (!__any(missing)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) st[k] = wave_max_u64(v[k]);
+            st[4] = __any(bad) ? 1 : 0;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        ++spins;
+        if ((spins & 15) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+        if (spins > (1u << 18)) {
+            if (lane_id() == 0) __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0;
+        }
+    }
+    if (st[4]) { st[0] = st[1] = st[2] = st[3] = 0; }
+    const Desc d = make_desc_f32(jb, st);
+    if (write_meta && lane_id() == 0) {
+        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+        meta[j] = m;
+    }
+    return gran_encode(d);
+}
 
-    for (int64_t it = blockIdx.x; it < total_items; it += gridDim.x) {
-        j = find_job_item(jobs, j, njobs, it);
+// 512 lanes x 32 values: the item is one 16,384-element pack tile, a lane's registers hold first its 32
+// raw values, then (in place) their pixel indices, then its packed group -- never two of these at once.
+constexpr int kThreadsR = 512;
+constexpr int kLdsR = kThreadsR * kStride32 * 4;     // 73,728 B: two workgroups per CU
+static_assert(kItem == kThreadsR * kGroup, "one lane packs one group of the item");
+
+__global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
+                                                                 int64_t total_items, const int* __restrict__ item_job,
+                                                                 ItemRec* __restrict__ recs,
+                                                                 uint32_t gen, uint32_t* __restrict__ abort_flag,
+                                                                 Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsR / 4];
+    __shared__ float red[4][kThreadsR / 64];
+    __shared__ int redbad[kThreadsR / 64];
+    __shared__ uint64_t shared_slot;
+    constexpr int kV = kItem / (4 * kThreadsR);        // 16-byte loads per lane per item (8)
+    const int tid = threadIdx.x;
+    MNW_STAMP_DECL
+    MNW_STAMP_START
+
+    // e[] holds the lane's 32 elements of the current item: first the raw float bits, later (in place)
+    // their pixel indices.  Once they are staged in LDS the registers are free again and the NEXT item's
+    // loads are issued into them, so that they fly while this item is packed and stored.  (A second
+    // register set would spill, and a spill reload queues behind the in-flight loads: memory operations
+    // complete in issue order.)
+    u32x4 e[kV];
+    int jn = 0;                 // job of the item in e[]
+    bool pfull = false;         // e[] holds a (full) item
+    int64_t it = blockIdx.x;
+    if (it < total_items) {
+        jn = item_job[it];
+        const DevJob jb = jobs[jn];
+        const int64_t base = (it - jb.tile0) * kItem;
+        pfull = base + kItem <= jb.n;
+        if (pfull) {
+#pragma unroll
+            for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>((const float*)jb.src + base + 4 * (k * kThreadsR + tid));
+        }
+    }
+
+    for (; it < total_items; it += gridDim.x) {
+        const int j = jn;
         const DevJob jb = jobs[j];
         const float* __restrict__ x = (const float*)jb.src;
         const int64_t base = (it - jb.tile0) * kItem;
-        const bool full = base + kItem <= jb.n;
+        const bool full = pfull;
+        // where the next item lives: looked up now (scalar loads overlap the work below), loaded into
+        // e[] as soon as this item's values have been staged
+        const int64_t nit = it + gridDim.x;
+        const float* xn = nullptr;
+        int64_t nbase = 0;
+        bool nfull = false;
+        if (nit < total_items) {
+            jn = item_job[nit];
+            const DevJob jbn = jobs[jn];
+            nbase = (nit - jbn.tile0) * kItem;
+            nfull = nbase + kItem <= jbn.n;
+            xn = (const float*)jbn.src;
+        }
+        auto load_next = [&]() {
+            pfull = nfull;
+            if (nfull) {
+#pragma unroll
+                for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(xn + nbase + 4 * (k * kThreadsR + tid));
+            }
+        };
 
-        // ---- load + statistics -------------------------------------------------------------------
-        // e[] holds the lane's 64 elements: first the raw float bits, later (in place) their pixel indices
-        u32x4 e[kV];
+        // ---- statistics of this item's values (loaded ahead) ---------------------------------------
         FStat s = {INFINITY, -INFINITY, -INFINITY, INFINITY, false};
         const float xh = jb.xh;
         if (full) {
-#pragma unroll
-            for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(x + base + 4 * (k * kThreads + tid));
 #pragma unroll
             for (int k = 0; k < kV; ++k) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) fstat_add(s, __uint_as_float(e[k][c]), xh);
             }
         } else {
-            for (int64_t i = base + tid; i < jb.n; i += kThreads) fstat_add(s, ldg<float>(x + i), xh);
+            for (int64_t i = base + tid; i < jb.n; i += kThreadsR) fstat_add(s, ldg<float>(x + i), xh);
         }
+        MNW_STAMP(0)      // wait for the loads + per-lane statistics
         float mn = wave_min(s.mn), mx = wave_max(s.mx), mxlo = wave_max(s.mxlo), mnhi = wave_min(s.mnhi);
         int bad = __any(s.bad);
         __syncthreads();
@@ -916,36 +1018,30 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_reg_f32(const DevJob* __
         }
         __syncthreads();
 
-        // ---- wave 0: publish the statistics, count the item in, finalize the block if it is complete.
-        //      waves 1-3 meanwhile: floats -> pixel indices (descriptor independent part of the quantize)
+        // ---- publish the item's record (wave 0, lanes 0..3: one 8-byte sc1 store each) --------------
+        if (tid < 4) {
+            float a = red[0][0], b2 = red[1][0], c2 = red[2][0], dd = red[3][0];
+            int bd = redbad[0];
+#pragma unroll
+            for (int w = 1; w < kThreadsR / 64; ++w) {
+                a = fminf(a, red[0][w]); b2 = fmaxf(b2, red[1][w]);
+                c2 = fmaxf(c2, red[2][w]); dd = fminf(dd, red[3][w]);
+                bd |= redbad[w];
+            }
+            uint32_t val;
+            if (tid == 0) val = bd ? 0 : fkey(b2);
+            else if (tid == 1) val = bd ? 0 : (uint32_t)~fkey(a);
+            else if (tid == 2) val = (bd || c2 == -INFINITY) ? 0 : fkey(c2);
+            else val = (bd || dd == INFINITY) ? 0 : (uint32_t)~fkey(dd);
+            const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (bd ? kRecBad : 0u)) << 32);
+            __hip_atomic_store(&recs[it].g[tid], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        MNW_STAMP(1)      // workgroup reduction + publish
+
+        // ---- floats -> pixel indices (descriptor independent), all waves ------------------------------
         const float low = jb.low, dx = jb.dxq;
         const double rdx = jb.rdx;
         bool tiny = false;
-        if (wave_id() == 0) {
-            if (tid < 5) {
-                float a = red[0][0], b = red[1][0], c2 = red[2][0], dd = red[3][0];
-                int bd = redbad[0];
-#pragma unroll
-                for (int w = 1; w < kThreads / 64; ++w) {
-                    a = fminf(a, red[0][w]); b = fmaxf(b, red[1][w]);
-                    c2 = fmaxf(c2, red[2][w]); dd = fminf(dd, red[3][w]);
-                    bd |= redbad[w];
-                }
-                uint64_t val;
-                if (tid == 0) val = bd ? 0 : fkey(b);
-                else if (tid == 1) val = bd ? 0 : (uint32_t)~fkey(a);
-                else if (tid == 2) val = (bd || c2 == -INFINITY) ? 0 : fkey(c2);
-                else if (tid == 3) val = (bd || dd == INFINITY) ? 0 : (uint32_t)~fkey(dd);
-                else val = bd ? 1 : 0;
-                uint64_t* rec = stats + ((int64_t)j * kStatSlots + slot) * kStatWords;
-                if (val != 0) atomicMax((unsigned long long*)(rec + tid), (unsigned long long)val);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // statistics drained
-            uint32_t before = 0;
-            if (tid == 0) before = __hip_atomic_fetch_add(&sync[j].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            before = __builtin_amdgcn_readfirstlane(before);
-            if (before + 1 == (uint32_t)items_of(jb.n)) finalize_job_f32(jobs, j, stats, sync, meta);
-        }
         if (full) {
 #pragma unroll
             for (int k = 0; k < kV; ++k) {
@@ -957,71 +1053,77 @@ __global__ __launch_bounds__(kThreads, 4) void k_encode_reg_f32(const DevJob* __
                 }
             }
         }
+        MNW_STAMP(2)      // convert
 
-        // ---- the block's descriptor ----------------------------------------------------------------
-        uint64_t gran;
-        if (!get_granule<true>(sync, abort_flag, j, 0, &shared_slot, &gran)) return;
+        // ---- the block's descriptor: wave 0 sweeps the records, everybody else waits at the barrier ---
+        if (wave_id() == 0) {
+            const uint64_t g = sweep_block_f32(jobs, j, recs, gen, abort_flag, meta, it == jb.tile0);
+            if (lane_id() == 0) shared_slot = g;
+        }
+        __syncthreads();
+        const uint64_t gran = shared_slot;
+        __syncthreads();
+        MNW_STAMP(3)      // sweep (wave 0) + barrier
+        if (!(gran & kGranReady)) return;                  // aborted
         const Desc d = gran_decode(gran, jb.n);
         const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
-        if (!ok) continue;
+        if (!ok) { load_next(); continue; }
         const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
         const int32_t pmin = (int32_t)d.pmin;
         const uint32_t imin = (uint32_t)(int32_t)d.imin, pix = (uint32_t)jb.pixels;
         const bool per = jb.periodic == 1;
         const int redo = __any(tiny);                  // a quotient below the float32 normal range: IEEE division
 
-        // ---- re-base, pack, store: two pack tiles of 8,192 elements ----------------------------------
+        // ---- re-base, stage, pack, store: one 16,384-element tile ------------------------------------
+        if (full) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t tbase = base + (int64_t)h * kTile;
-            if (tbase >= jb.n) break;
-            if (full) {
-#pragma unroll
-                for (int k = 0; k < kV / 2; ++k) {
-                    u32x4 r;
-                    if (__builtin_expect(redo, 0)) {
-                        // a tiny quotient somewhere in this wave: redo this lane's own elements with the
-                        // IEEE division (the floats are reloaded: the registers hold indices by now)
-                        const f32x4 xv = ldg<f32x4>(x + tbase + 4 * (k * kThreads + tid));
-                        for (int c = 0; c < 4; ++c) e[h * (kV / 2) + k][c] = (uint32_t)(int32_t)quant_floor(xv[c], low, dx);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        uint32_t uq = e[h * (kV / 2) + k][c];
-                        if (per && (int32_t)uq < pmin) uq += pix;          // bound(), group.go:374-382
-                        r[c] = uq - imin;                                  // group.go:247
-                    }
-                    *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreads + tid))) = r;
+            for (int k = 0; k < kV; ++k) {
+                u32x4 r;
+                if (__builtin_expect(redo, 0)) {
+                    // a tiny quotient somewhere in this wave: redo this lane's own elements with the
+                    // IEEE division (the floats are reloaded: the registers hold indices by now)
+                    const f32x4 xv = ldg<f32x4>(x + base + 4 * (k * kThreadsR + tid));
+                    for (int c = 0; c < 4; ++c) e[k][c] = (uint32_t)(int32_t)quant_floor(xv[c], low, dx);
                 }
-            } else {
-                for (int i = tid; i < kTile; i += kThreads) {
-                    uint32_t r = 0;
-                    if (tbase + i < jb.n) {
-                        const int32_t qq = (int32_t)quant_floor(ldg<float>(x + tbase + i), low, dx);
-                        uint32_t uq = (uint32_t)qq;
-                        if (per && qq < pmin) uq += pix;
-                        r = uq - imin;
-                    }
-                    lds[stage32_idx(i)] = r;
-                }
-            }
-            lds_barrier();
-            uint32_t g[kGroup];
 #pragma unroll
-            for (int k = 0; k < kGroup / 4; ++k) {
-                const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
-                g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+                for (int c = 0; c < 4; ++c) {
+                    uint32_t uq = e[k][c];
+                    if (per && (int32_t)uq < pmin) uq += pix;          // bound(), group.go:374-382
+                    r[c] = uq - imin;                                  // group.go:247
+                }
+                *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreadsR + tid))) = r;
             }
-            lds_barrier();
-            pack_group32(g, b, lds + tid * b);
-            lds_barrier();
-            const int64_t tile_byte0 = tbase / 8 * b;
-            int64_t tile_bytes = (int64_t)kTile / 8 * b;
-            if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-            store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
-            lds_barrier();
+        } else {
+            for (int i = tid; i < kItem; i += kThreadsR) {
+                uint32_t r = 0;
+                if (base + i < jb.n) {
+                    const int32_t qq = (int32_t)quant_floor(ldg<float>(x + base + i), low, dx);
+                    uint32_t uq = (uint32_t)qq;
+                    if (per && qq < pmin) uq += pix;
+                    r = uq - imin;
+                }
+                lds[stage32_idx(i)] = r;
+            }
         }
+        load_next();         // the values are staged: the next item goes into the same registers
+        lds_barrier();
+        uint32_t g[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup / 4; ++k) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+            g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+        }
+        lds_barrier();
+        pack_group32(g, b, lds + tid * b);
+        lds_barrier();
+        const int64_t tile_byte0 = base / 8 * b;
+        int64_t tile_bytes = (int64_t)kItem / 8 * b;
+        if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+        store_tile<kThreadsR>(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+        lds_barrier();
+        MNW_STAMP(4)      // stage + pack + store
     }
+    MNW_STAMP_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1463,13 +1565,15 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
     hipLaunchKernelGGL(k_encode_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, gtile, gjob, ngroups, stats, (JobSync*)sync, abort_flag, meta);
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
-void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, uint64_t* stats, void* sync,
-                           uint32_t* abort_flag, Meta* meta) {
-    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, items, stats, (JobSync*)sync, abort_flag, meta);
+void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
+                           uint32_t gen, uint32_t* abort_flag, Meta* meta) {
+    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag, meta);
 }
+size_t item_rec_bytes() { return sizeof(ItemRec); }
+int reg_max_items_per_block() { return kMaxSweep; }
 int encode_reg_f32_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32, kThreads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32, kThreadsR, 0) != hipSuccess) return 0;
     return n;
 }
 int encode_f32_blocks_per_cu() {

@@ -52,8 +52,9 @@ def run(B, grid, group_mb, fused=0, single=1):
     torch.cuda.synchronize()
     kt = ctx.timing_get(); ctx.timing_enable(False)
     ks = "  ".join("%s %.1fus x%d" % (k.replace("k_", ""), 1e3 * v["total_ms"] / max(v["launches"], 1), v["launches"] // a.reps) for k, v in kt.items() if v["launches"])
-    te = timeit(lambda: (ctx.encode_blocks_async(ej, stream=stream), ctx.encode_blocks_finish()))
-    td = timeit(lambda: ctx.decode_blocks(dj, stream=stream))
+    eb, db = ctx.enc_batch(ej), ctx.dec_batch(dj)
+    te = timeit(lambda: (ctx.encode_blocks_async(eb, stream=stream), ctx.encode_blocks_finish()))
+    td = timeit(lambda: ctx.decode_blocks(db, stream=stream))
     pb = sum(m.nbytes for m in metas)
     alg = 4.0 * N + pb
     print("B=2^%-4.1f grid=%-5d group=%-4dMB fused=%d single=%d  enc best %.1f us avg %.1f us (%.2f TB/s alg)   dec best %.1f us avg %.1f (%.2f TB/s alg)" % (
