@@ -12,7 +12,7 @@
 #include <vector>
 
 namespace mnw {
-void launch_prepare(hipStream_t, const void*, void*, int64_t, void*, int64_t, void*, int64_t);
+void launch_prepare(hipStream_t, const void*, void*, int64_t, void*, int64_t, void*, int64_t, const void* = nullptr, void* = nullptr, int64_t = 0);
 void launch_reduce_f32(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*, void*, Meta*);
 size_t job_sync_bytes();
 void launch_reduce_i64(hipStream_t, int, const DevJob*, int, int64_t, uint64_t*);
@@ -20,9 +20,10 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, Meta*);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*);
 size_t item_rec_bytes();
 int reg_max_items_per_block();
+int64_t reg_item_elems();
 int encode_reg_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
@@ -66,6 +67,10 @@ struct JobSlot {
     Meta* d_meta = nullptr;       // device address of h_meta
     uint32_t* h_sync = nullptr;   // abort flag of the fused launch, copied here by a 1-word k_prepare
     uint32_t* d_hsync = nullptr;  // device address of h_sync
+    // single-read encode: the job of every item (pinned, coherent) and its device copy, grow-only
+    int* h_itemjob = nullptr;
+    int* d_itemjob = nullptr;
+    size_t cap_itemjob = 0;
     hipEvent_t consumed = nullptr;
     bool in_flight = false;
 };
@@ -110,9 +115,6 @@ struct mnw_ctx {
     void* d_recs = nullptr;      // single read: one published statistics record per item (grow-only)
     size_t cap_recs = 0;
     uint32_t reg_gen = 0;        // generation tag of the records of the current batch (never 0)
-    int* h_itemjob = nullptr;    // single read: job of every item (pinned, coherent) and its device copy
-    int* d_itemjob = nullptr;
-    size_t cap_itemjob = 0;
     int fused_blocks_per_cu = 0; // co-resident workgroups of k_encode_f32 per CU (occupancy query)
     int64_t fused_aborts = 0;    // fused launches that fell back to the two-kernel path
     int pend_nfloat = 0;         // device slots [0, pend_nfloat) of the pending batch are float jobs
@@ -148,6 +150,8 @@ void free_slot(JobSlot& sl) {
         hipFree(sl.d_up); hipHostFree(sl.h_up); hipFree(sl.d_stats); hipHostFree(sl.h_meta); hipHostFree(sl.h_sync);
     }
     sl.d_up = nullptr; sl.d_jobs = nullptr; sl.cap = 0;
+    if (sl.d_itemjob) { hipFree(sl.d_itemjob); hipHostFree(sl.h_itemjob); }
+    sl.d_itemjob = nullptr; sl.h_itemjob = nullptr; sl.cap_itemjob = 0;
 }
 
 // next ring slot with room for n jobs; waits (host side) only if that slot's previous batch is
@@ -391,13 +395,13 @@ int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int 
 int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
     if (c->reg_blocks_per_cu == 0) {
         int occ = mnw::encode_reg_f32_blocks_per_cu();
-        c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 2 ? 2 : occ);     // 512-thread workgroups, 72 KB LDS: two per CU
+        c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);     // 256-thread workgroups, 36 KB LDS: four per CU
     }
     if (c->reg_blocks_per_cu < 1) return 1;
     int grid = c->cus * c->reg_blocks_per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
     const int max_items = grid < mnw::reg_max_items_per_block() ? grid : mnw::reg_max_items_per_block();
-    const int64_t item = 2 * mnw::kTile;
+    const int64_t item = mnw::reg_item_elems();
     int64_t items = 0;
     for (int k = 0; k < nfloat; ++k) {
         const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
@@ -415,33 +419,38 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         HIPCHK(c, hipMemsetAsync(c->d_recs, 0, want, s));      // tags of a fresh buffer must not match any generation
         c->cap_recs = want;
     }
-    if ((size_t)items > c->cap_itemjob) {
-        if (c->d_itemjob) { HIPCHK(c, hipStreamSynchronize(s)); hipFree(c->d_itemjob); hipHostFree(c->h_itemjob); }
-        c->d_itemjob = nullptr; c->h_itemjob = nullptr; c->cap_itemjob = 0;
-        const size_t want = (size_t)items + (size_t)items / 2 + 1024;
-        HIPCHK(c, hipMalloc((void**)&c->d_itemjob, want * sizeof(int)));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_itemjob, want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
-        c->cap_itemjob = want;
-    } else if (c->d_itemjob) {
-        // the table of the previous single-read batch may still be read by the copy kernel below
-        HIPCHK(c, hipStreamSynchronize(s));
+    if ((size_t)items > sl->cap_itemjob) {
+        // the slot is not in flight (acquire_slot waited for its previous batch)
+        if (sl->d_itemjob) { hipFree(sl->d_itemjob); hipHostFree(sl->h_itemjob); }
+        sl->d_itemjob = nullptr; sl->h_itemjob = nullptr; sl->cap_itemjob = 0;
+        const size_t want = ((size_t)items + (size_t)items / 2 + 1024 + 3) / 4 * 4;
+        HIPCHK(c, hipMalloc((void**)&sl->d_itemjob, want * sizeof(int)));
+        HIPCHK(c, hipHostMalloc((void**)&sl->h_itemjob, want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+        sl->cap_itemjob = want;
     }
     for (int k = 0; k < nfloat; ++k) {
         const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
-        for (int64_t i = 0; i < ni; ++i) c->h_itemjob[i0 + i] = k;
+        for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k;
     }
-    if (items > 0) mnw::launch_prepare(s, c->h_itemjob, c->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16, nullptr, 0, nullptr, 0);
     c->reg_gen = (c->reg_gen + 1) & 0x7fffffffu;
     if (c->reg_gen == 0) c->reg_gen = 1;
-    int rc = prepare_slot(c, sl, s, nslot_all, true);
-    if (rc) return rc;
+    sl->h_sync[0] = 0;                        // the kernel raises it (pinned host word) if it gives up
+    // one small launch: job records and item table to device memory, abort word zeroed
+    // (int jobs of the same batch, slots [nfloat, nslot_all), go through the two-kernel path afterwards and need
+    // their statistics and synchronisation words zeroed; the float jobs here need neither)
+    const bool ints = nslot_all > nfloat;
+    mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
+                        ints ? sl->d_stats : nullptr, ints ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot_all) : 0,
+                        sl->d_sync, (int64_t)(sizeof(uint32_t) * kSyncPad + (ints ? sl->sync_stride * nslot_all : 0)),
+                        sl->h_itemjob, sl->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16);
+    HIPCHK(c, hipGetLastError());
     if (items > 0) {
         if (items < grid) grid = (int)items;
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
-        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, c->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_meta);
+        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
+                                   sl->d_meta);
     }
     HIPCHK(c, hipGetLastError());
-    mnw::launch_prepare(s, abort_ptr(sl), sl->d_hsync, 4, nullptr, 0, nullptr, 0);   // abort flag -> pinned host word
     return MNW_OK;
 }
 
@@ -574,7 +583,6 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_q) hipFree(c->d_q);
     if (c->d_state) hipFree(c->d_state);
     if (c->d_recs) hipFree(c->d_recs);
-    if (c->d_itemjob) { hipFree(c->d_itemjob); hipHostFree(c->h_itemjob); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return MNW_OK;

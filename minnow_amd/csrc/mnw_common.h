@@ -94,9 +94,7 @@ MNW_HD int precision_needed(uint64_t max) {
     if (max == ~0ull) return -1;
     uint64_t m1 = max + 1;
     if (m1 <= (1ull << 48)) {                    // exact region: bit length of max
-        int b = 0;
-        while (b < 64 && (max >> b) != 0) b++;
-        return b;
+        return max == 0 ? 0 : 64 - __builtin_clzll(max);
     }
     double x = (double)m1;                       // uint64 -> float64, round to nearest even
     int e;

@@ -71,6 +71,29 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     return v;
 }
 
+// Wave reductions on the DPP crossbar (no LDS traffic, unlike __shfl_xor's ds_bpermute): butterfly inside
+// each row of 16 lanes (two quad permutes, half-row mirror, row mirror), then the four row results via
+// v_readlane.  The result is wave-uniform.
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce_dpp(T v, Op op) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    auto dpp = [](T x, auto ctrl) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));      // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));      // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));     // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));     // row_mirror
+    const T r0 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const T r1 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const T r2 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const T r3 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_min_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fminf(a, b); }); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) { return wave_reduce_dpp(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+
 // job of tile t: last j with jobs[j].tile0 <= t (jobs with n == 0 own no tile and are never hit
 // because the next job has the same tile0 and the search takes the last one)
 __device__ __forceinline__ int find_job(const DevJob* jobs, int njobs, int64_t t) {
@@ -511,6 +534,35 @@ __device__ __forceinline__ void pack_group32(const uint32_t (&v)[kGroup], uint32
     }
 }
 
+// pack_group32 with the width as a compile-time constant per case: straight-line code, immediate shifts,
+// no scalar compare/branch per element (b is wave-uniform, 1..32).
+__device__ __forceinline__ void pack_group32_switch(const uint32_t (&v)[kGroup], uint32_t b, uint32_t* __restrict__ out) {
+#define MNW_PACK_CASE(B) case B: pack_group32(v, B, out); break;
+    switch (b) {
+        MNW_PACK_CASE(1) MNW_PACK_CASE(2) MNW_PACK_CASE(3) MNW_PACK_CASE(4) MNW_PACK_CASE(5) MNW_PACK_CASE(6) MNW_PACK_CASE(7)
+        MNW_PACK_CASE(8) MNW_PACK_CASE(9) MNW_PACK_CASE(10) MNW_PACK_CASE(11) MNW_PACK_CASE(12) MNW_PACK_CASE(13)
+        MNW_PACK_CASE(14) MNW_PACK_CASE(15) MNW_PACK_CASE(16) MNW_PACK_CASE(17) MNW_PACK_CASE(18) MNW_PACK_CASE(19)
+        MNW_PACK_CASE(20) MNW_PACK_CASE(21) MNW_PACK_CASE(22) MNW_PACK_CASE(23) MNW_PACK_CASE(24) MNW_PACK_CASE(25)
+        MNW_PACK_CASE(26) MNW_PACK_CASE(27) MNW_PACK_CASE(28) MNW_PACK_CASE(29) MNW_PACK_CASE(30) MNW_PACK_CASE(31)
+        MNW_PACK_CASE(32)
+        default: break;
+    }
+#undef MNW_PACK_CASE
+}
+
+// three-input float min / max without the compiler's canonicalising v_max_f32 x,x in front (a NaN among
+// the inputs is flagged separately, so what the instruction does with it does not matter)
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+// int32(floor(x)) in one instruction
+__device__ __forceinline__ int32_t cvt_floor_i32(float x) {
+    int32_t r; asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x)); return r;
+}
+
 // 33..64-bit values: each is the field pair (low 32 bits, high b-32 bits) of the same LSB-first stream.
 // Register-light form for the rare wide path: the lane's 32 values are read from LDS one at a time
 // (`in`, 8-byte aligned) and its b words go to a separate LDS region (`out`).
@@ -840,29 +892,47 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 // ------------------------------------------------------------------------------------------------
 // single-read float32 encode (k_encode_reg_f32): the block is read ONCE.
 //
-// An item = 16,384 consecutive elements of one block = 64 values per lane, which stay in registers
-// from the load to the pack.  Workgroup w takes items w, w+G, w+2G, ... of the batch-wide item
-// numbering.  Per item: load -> fold the raw floats into the item's four statistics (as k_reduce_f32)
-// -> PUBLISH them as one 32-byte record of four self-validating 8-byte words {value, tag} (tag = this
-// batch's generation; one sc1 store each, no atomics, nothing to zero) -> wave 0 sweeps the records of
-// all items of the block until every tag is present and derives the block's descriptor itself (every
-// workgroup of the block computes the same descriptor; no counter, no "last arrival", one memory hop)
-// -> re-base, pack and store from the registers (one 16,384-element pack tile, 512 lanes x 32).  While wave 0 sweeps,
-// the other waves already turn their floats into pixel indices (the float64 multiply, floor and convert
-// need nothing from the descriptor).  This is the all-gather of tagged granules of
-// MI355X_MICROARCH.md ("allgather", "Valid forms": R2's granule needs no ordering).
+// An item = 8,192 consecutive elements of one block = 32 values per lane of a 256-lane workgroup.
+// Workgroup w takes items w, w+G, w+2G, ... of the batch-wide item numbering and always has two of them
+// on chip: item i in the registers e[] (loaded, or still in flight from HBM) and item i-1 parked as raw
+// floats in LDS, its statistics PUBLISHED and waiting for the rest of its block.  Per loop trip:
 //
-// No deadlock if every block has at most G items and all G workgroups are resident: let m be the
-// smallest item any workgroup is blocked on.  Every item k of m's block is either < m (its owner has
-// moved past it, so its record is published) or in (m, m+G): its owner handles items congruent to k mod G
-// in increasing order and is blocked on an item >= m, which can only be k itself or a later one -- and a
-// workgroup publishes an item's record BEFORE it waits for that item's block.  The host only sends
-// blocks of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; spins are bounded
-// and a timeout aborts the launch (the host then reruns the batch through the two-kernel path).
+//   1. start the loads of the records of item i-1's block (see 3)
+//   2. fold item i's floats into the four statistics of k_reduce_f32 and publish them as one 32-byte
+//      record of four self-validating 8-byte words {value, tag} (tag = this batch's generation; one sc1
+//      store each, no atomics, nothing to zero)
+//   3. wave 0 derives the descriptor of item i-1's block from the records of all its items -- published
+//      a whole trip ago, so they are normally all there; every workgroup of the block computes the same
+//      descriptor: no counter, no "last arrival", one memory hop -- while the other waves turn i-1's
+//      floats into pixel indices; re-base, pack, store
+//   4. park item i in LDS and start the loads of item i+1
+//
+// The skew between the workgroups of a block hides behind a whole trip; the HBM latency of step 4's
+// loads is covered the ordinary way, by the other three workgroups of the CU (36 KB of LDS and <= 128
+// registers: four workgroups per CU).  A deeper pipeline (item i+1 in flight while i-1 is packed) needs
+// a second LDS buffer, halves the occupancy and measured slower: a trip is latency bound (its duration
+// barely depends on how many workgroups share the CU), so resident workgroups are what count.
+// This is the all-gather of tagged granules of MI355X_MICROARCH.md ("allgather", "Valid forms": R2's
+// granule needs no ordering).
+//
+// Memory operations of a wave complete in issue order, hence: the record loads are issued before
+// anything else of the trip, every barrier is the LDS-only one, and the kernel must not spill.
+//
+// No deadlock if every block has at most G items and all G workgroups are resident: a workgroup
+// publishes item i before it waits for item i-1's block and never waits before publishing.  Let m be
+// the smallest item any workgroup is blocked on.  An item k of m's block is either < m (published: its
+// owner is past it) or in (m, m+G): its owner handles the items congruent to k mod G in increasing
+// order, is at worst blocked on an item m' >= m of that residue class and has published m'+G already;
+// k < m+G <= m'+G and k = m' (mod G) give k <= m', so k's record is out.  The host only sends blocks
+// of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; spins are bounded and a
+// timeout aborts the launch (the host then reruns the batch through the two-kernel path).
 // HBM traffic = algorithmic bytes: 4 B/element read + b/8 B/element written.
 // ------------------------------------------------------------------------------------------------
-constexpr int kItem = 2 * kTile;
-constexpr int kMaxSweep = 256;                      // items per block the sweep handles (2^22 elements)
+constexpr int kThreadsR = 256;
+constexpr int kItem = kThreadsR * kGroup;           // 8,192 elements: one lane packs one group of the item
+constexpr int kBufR = kThreadsR * kStride32;        // dwords of one parked item (padded stage layout)
+constexpr int kLdsR = kBufR * 4;                    // 36,864 B: four workgroups per CU
+constexpr int kMaxSweep = 512;                      // items per block the sweep handles (2^22 elements)
 __device__ __forceinline__ int64_t items_of(int64_t n) { return (n + kItem - 1) / kItem; }
 
 struct ItemRec {                                     // 32 bytes: four {value: low 32, tag: high 32} words
@@ -870,26 +940,59 @@ struct ItemRec {                                     // 32 bytes: four {value: l
 };
 constexpr uint32_t kRecBad = 0x80000000u;            // tag bit 31: the item held a NaN / infinity
 
-// job of item t (DevJob.tile0 holds the job's first ITEM in this launch's numbering)
-__device__ __forceinline__ int find_job_item(const DevJob* jobs, int lo, int njobs, int64_t t) {
-    int hi = njobs - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+// wave 0 only.  Descriptor word of job j from the swept statistics; the owner of the block's first item
+// records the metadata.  (Inlined: a call would save and reload a register through scratch, and that
+// reload would queue behind the wave's streaming loads.)  Lanes 0..3 quantize one survivor each, so the
+// IEEE division sequence runs once, not four times.
+__device__ __forceinline__ uint64_t desc_from_sweep_f32(const DevJob& jb, int j, uint32_t v0, uint32_t v1,
+                                                        uint32_t v2, uint32_t v3, bool bad, Meta* __restrict__ meta,
+                                                        bool write_meta) {
+    Desc d = {0, 0, 0, 0, 0};
+    const int l = lane_id();
+    const uint32_t key = l == 0 ? v0 : l == 1 ? ~v1 : l == 2 ? v2 : ~v3;
+    int64_t ql = 0;
+    const bool okl = quant_i64(funkey(key), jb.low, jb.dxq, &ql);
+    const bool has_lo = v2 != 0, has_hi = v3 != 0;
+    const uint64_t okmask = __ballot(okl);
+    const bool ok = (okmask & 3) == 3 && (!has_lo || (okmask & 4)) && (!has_hi || (okmask & 8));
+    const int64_t mx0 = __shfl(ql, 0), mn0 = __shfl(ql, 1), mxlo = __shfl(ql, 2), mnhi = __shfl(ql, 3);
+    uint64_t maxdelta = 0;
+    if (bad || !ok) {
+        d.status = (int)kNeedsExact;
+    } else if (jb.periodic == 1) {
+        // same decisions as make_desc_f32
+        if (mn0 < 0 || mx0 >= jb.pixels || jb.pixels > 0x7fffffffll) d.status = (int)kNeedsExact;
+        else {
+            const int64_t h = jb.pixels / 2;
+            if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+            else if (has_lo && has_hi && (mxlo + jb.pixels) - mnhi + 1 <= h) {
+                d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jb.pixels - mnhi);
+            } else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+        }
+    } else {
+        if (mn0 < -0x80000000ll || mx0 > 0x7fffffffll) d.status = (int)kNeedsExact;
+        else { d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
     }
-    return lo;
+    if (d.status == 0) {
+        d.bits = precision_needed(maxdelta);
+        d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jb.n);
+        if (d.nbytes > jb.cap) d.status = -5;
+    }
+    if (write_meta && l == 0) {
+        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+        meta[j] = m;
+    }
+    return gran_encode(d);
 }
 
-// wave 0 only (not inlined: its float64 temporaries must not be live beside the 64 data registers).
-// Sweeps the block's records until all are present, then returns the descriptor word (0 on abort).
+// wave 0 only, slow path: some record of the block was not there yet when the workgroup looked.  Polls
+// until all are present, then returns the descriptor word (0 on abort).
 __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __restrict__ jobs, int j,
                                                               const ItemRec* __restrict__ recs, uint32_t gen,
-                                                              uint32_t* __restrict__ abort_flag, Meta* __restrict__ meta,
-                                                              bool write_meta) {
-    const DevJob jb = jobs[j];
-    const int nitems = (int)items_of(jb.n);
-    const ItemRec* r0 = recs + jb.tile0;
-    uint64_t st[5];
+                                                              uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ abort_host,
+                                                              Meta* __restrict__ meta, bool write_meta) {
+    const int nitems = (int)items_of(jobs[j].n);
+    const ItemRec* r0 = recs + jobs[j].tile0;
     uint32_t spins = 0;
     for (;;) {
         uint32_t v[4] = {0, 0, 0, 0};
@@ -906,124 +1009,176 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
             }
         }
         if (!__any(missing)) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) st[k] = wave_max_u64(v[k]);
-            st[4] = __any(bad) ? 1 : 0;
-            break;
+            const DevJob jb = jobs[j];
+            return desc_from_sweep_f32(jb, j, wave_max_dpp(v[0]), wave_max_dpp(v[1]), wave_max_dpp(v[2]), wave_max_dpp(v[3]),
+                                       __any(bad), meta, write_meta);
         }
         __builtin_amdgcn_s_sleep(4);
         ++spins;
         if ((spins & 15) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
         if (spins > (1u << 18)) {
-            if (lane_id() == 0) __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane_id() == 0) {
+                __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word
+            }
             return 0;
         }
     }
-    if (st[4]) { st[0] = st[1] = st[2] = st[3] = 0; }
-    const Desc d = make_desc_f32(jb, st);
-    if (write_meta && lane_id() == 0) {
-        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
-        meta[j] = m;
-    }
-    return gran_encode(d);
 }
 
-// 512 lanes x 32 values: the item is one 16,384-element pack tile, a lane's registers hold first its 32
-// raw values, then (in place) their pixel indices, then its packed group -- never two of these at once.
-constexpr int kThreadsR = 512;
-constexpr int kLdsR = kThreadsR * kStride32 * 4;     // 73,728 B: two workgroups per CU
-static_assert(kItem == kThreadsR * kGroup, "one lane packs one group of the item");
+#ifdef MNW_STAMPS
+__device__ unsigned long long g_slow_sweeps = 0;
+#endif
 
 __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
                                                                  int64_t total_items, const int* __restrict__ item_job,
                                                                  ItemRec* __restrict__ recs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
-                                                                 Meta* __restrict__ meta) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kLdsR / 4];
+                                                                 uint32_t* __restrict__ abort_host, Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kBufR];
     __shared__ float red[4][kThreadsR / 64];
     __shared__ int redbad[kThreadsR / 64];
+    __shared__ uint32_t swv[4][kThreadsR / 64];
+    __shared__ uint32_t swf[kThreadsR / 64];
     __shared__ uint64_t shared_slot;
     constexpr int kV = kItem / (4 * kThreadsR);        // 16-byte loads per lane per item (8)
+    constexpr int kW = kThreadsR / 64;
     const int tid = threadIdx.x;
     MNW_STAMP_DECL
     MNW_STAMP_START
 
-    // e[] holds the lane's 32 elements of the current item: first the raw float bits, later (in place)
-    // their pixel indices.  Once they are staged in LDS the registers are free again and the NEXT item's
-    // loads are issued into them, so that they fly while this item is packed and stored.  (A second
-    // register set would spill, and a spill reload queues behind the in-flight loads: memory operations
-    // complete in issue order.)
+    // the item in e[] (all wave-uniform)
     u32x4 e[kV];
-    int jn = 0;                 // job of the item in e[]
-    bool pfull = false;         // e[] holds a (full) item
-    int64_t it = blockIdx.x;
-    if (it < total_items) {
-        jn = item_job[it];
-        const DevJob jb = jobs[jn];
-        const int64_t base = (it - jb.tile0) * kItem;
-        pfull = base + kItem <= jb.n;
-        if (pfull) {
-#pragma unroll
-            for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>((const float*)jb.src + base + 4 * (k * kThreadsR + tid));
-        }
-    }
-
-    for (; it < total_items; it += gridDim.x) {
-        const int j = jn;
-        const DevJob jb = jobs[j];
-        const float* __restrict__ x = (const float*)jb.src;
-        const int64_t base = (it - jb.tile0) * kItem;
-        const bool full = pfull;
-        // where the next item lives: looked up now (scalar loads overlap the work below), loaded into
-        // e[] as soon as this item's values have been staged
-        const int64_t nit = it + gridDim.x;
-        const float* xn = nullptr;
-        int64_t nbase = 0;
-        bool nfull = false;
-        if (nit < total_items) {
-            jn = item_job[nit];
-            const DevJob jbn = jobs[jn];
-            nbase = (nit - jbn.tile0) * kItem;
-            nfull = nbase + kItem <= jbn.n;
-            xn = (const float*)jbn.src;
-        }
-        auto load_next = [&]() {
-            pfull = nfull;
-            if (nfull) {
-#pragma unroll
-                for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(xn + nbase + 4 * (k * kThreadsR + tid));
-            }
-        };
-
-        // ---- statistics of this item's values (loaded ahead) ---------------------------------------
-        FStat s = {INFINITY, -INFINITY, -INFINITY, INFINITY, false};
-        const float xh = jb.xh;
-        if (full) {
+    int cj = 0;
+    int64_t cbase = 0, cn = 0;
+    const float* cx = nullptr;
+    float cxh = 0.0f;
+    auto locate = [&](int64_t t) {
+        cj = item_job[t];
+        cbase = (t - jobs[cj].tile0) * kItem;
+        cn = jobs[cj].n;
+        cx = (const float*)jobs[cj].src;
+        cxh = jobs[cj].xh;
+    };
+    auto issue = [&]() {
+        // (a block's last, partial item is not held in registers: its statistics and its parked copy are
+        // made by plain loops over global memory, see below)
+        if (cbase + kItem <= cn) {
 #pragma unroll
             for (int k = 0; k < kV; ++k) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) fstat_add(s, __uint_as_float(e[k][c]), xh);
+                const float* pk = cx + cbase + k * (4 * kThreadsR);     // wave-uniform part of the address
+                e[k] = ldg<u32x4>(pk + 4 * tid);
             }
-        } else {
-            for (int64_t i = base + tid; i < jb.n; i += kThreadsR) fstat_add(s, ldg<float>(x + i), xh);
         }
-        MNW_STAMP(0)      // wait for the loads + per-lane statistics
-        float mn = wave_min(s.mn), mx = wave_max(s.mx), mxlo = wave_max(s.mxlo), mnhi = wave_min(s.mnhi);
-        int bad = __any(s.bad);
-        __syncthreads();
-        if (lane_id() == 0) {
-            red[0][wave_id()] = mn; red[1][wave_id()] = mx;
-            red[2][wave_id()] = mxlo; red[3][wave_id()] = mnhi;
-            redbad[wave_id()] = bad;
-        }
-        __syncthreads();
+    };
 
-        // ---- publish the item's record (wave 0, lanes 0..3: one 8-byte sc1 store each) --------------
-        if (tid < 4) {
+    int64_t it = blockIdx.x;
+    bool have_cur = it < total_items;
+    if (have_cur) { locate(it); issue(); }
+    bool have_prev = false;
+    int pj = 0;                 // the parked item
+    int64_t pbase = 0, pit = 0;
+
+    while (have_cur || have_prev) {
+        const int sj = cj;
+        const int64_t sbase = cbase, sit = it;
+        const float xh = cxh;
+        const float* const sx = cx + cbase;
+        const int64_t srem = cn - cbase;                 // elements of item i (>= kItem: a full one)
+        const int64_t nit = it + gridDim.x;
+        const bool have_next = have_cur && nit < total_items;
+        // where the next item lives: scalar loads, started long before they are needed
+        if (have_next) locate(nit);
+
+        // ---- 1. the records of item i-1's block, one per lane (two for blocks of more than 256 items).
+        // Issued ahead of everything else of the trip that touches memory, used after the statistics.
+        DevJob pjb;
+        int pitems = 0;
+        uint64_t sw[2][4];
+        if (have_prev) {
+            pjb = jobs[pj];
+            pitems = (int)items_of(pjb.n);
+            const ItemRec* r0 = recs + pjb.tile0;
+            const uint64_t neutral = (uint64_t)gen << 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                sw[0][k] = tid < pitems ? __hip_atomic_load(&r0[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
+            if (pitems > kThreadsR) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    sw[1][k] = tid + kThreadsR < pitems
+                                   ? __hip_atomic_load(&r0[tid + kThreadsR].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
+            }
+        }
+
+        if (have_cur) {
+            // ---- 2. statistics of item i -----------------------------------------------------------------
+            float mn = INFINITY, mx = -INFINITY, mxlo = -INFINITY, mnhi = INFINITY;
+            bool nonfinite = false;
+            if (srem >= kItem) {
+#pragma unroll
+                for (int k = 0; k < kV; ++k) {
+#pragma unroll
+                    for (int c = 0; c < 4; c += 2) {
+                        const float x0 = __uint_as_float(e[k][c]), x1 = __uint_as_float(e[k][c + 1]);
+                        nonfinite |= __builtin_amdgcn_classf(x0, 0x207) | __builtin_amdgcn_classf(x1, 0x207);   // NaN, +-Inf
+                        mn = min3_raw(mn, x0, x1);
+                        mx = max3_raw(mx, x0, x1);
+                        const bool lo0 = x0 < xh, lo1 = x1 < xh;
+                        mxlo = max3_raw(mxlo, lo0 ? x0 : -INFINITY, lo1 ? x1 : -INFINITY);
+                        mnhi = min3_raw(mnhi, lo0 ? INFINITY : x0, lo1 ? INFINITY : x1);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int i = tid; i < (int)srem; i += kThreadsR) {
+                    const float x0 = ldg<float>(sx + i);
+                    nonfinite |= __builtin_amdgcn_classf(x0, 0x207);
+                    mn = fminf(mn, x0); mx = fmaxf(mx, x0);
+                    if (x0 < xh) mxlo = fmaxf(mxlo, x0); else mnhi = fminf(mnhi, x0);
+                }
+            }
+            MNW_STAMP(0)      // wait for the loads + per-lane statistics
+            mn = wave_min_dpp(mn); mx = wave_max_dpp(mx); mxlo = wave_max_dpp(mxlo); mnhi = wave_min_dpp(mnhi);
+            const int bad = __any(nonfinite);
+            if (lane_id() == 0) {
+                red[0][wave_id()] = mn; red[1][wave_id()] = mx;
+                red[2][wave_id()] = mxlo; red[3][wave_id()] = mnhi;
+                redbad[wave_id()] = bad;
+            }
+        }
+        if (have_prev) {
+            // fold what the record loads brought
+            uint32_t v[4] = {0, 0, 0, 0};
+            uint32_t bad = 0, missing = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && pitems <= kThreadsR) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t tag = (uint32_t)(sw[h][k] >> 32);
+                    missing |= (tag & ~kRecBad) != gen;
+                    bad |= tag & kRecBad;
+                    const uint32_t val = (uint32_t)sw[h][k];
+                    v[k] = val > v[k] ? val : v[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(v[k]);
+            const uint32_t fl = (__any(missing) ? 1u : 0u) | (__any(bad) ? 2u : 0u);
+            if (lane_id() == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) swv[k][wave_id()] = v[k];
+                swf[wave_id()] = fl;
+            }
+        }
+        lds_barrier();
+        if (have_cur && tid < 4) {
+            // publish the item's record (wave 0, lanes 0..3: one 8-byte sc1 store each)
             float a = red[0][0], b2 = red[1][0], c2 = red[2][0], dd = red[3][0];
             int bd = redbad[0];
 #pragma unroll
-            for (int w = 1; w < kThreadsR / 64; ++w) {
+            for (int w = 1; w < kW; ++w) {
                 a = fminf(a, red[0][w]); b2 = fmaxf(b2, red[1][w]);
                 c2 = fmaxf(c2, red[2][w]); dd = fminf(dd, red[3][w]);
                 bd |= redbad[w];
@@ -1034,94 +1189,103 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             else if (tid == 2) val = (bd || c2 == -INFINITY) ? 0 : fkey(c2);
             else val = (bd || dd == INFINITY) ? 0 : (uint32_t)~fkey(dd);
             const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (bd ? kRecBad : 0u)) << 32);
-            __hip_atomic_store(&recs[it].g[tid], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&recs[sit].g[tid], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        MNW_STAMP(1)      // workgroup reduction + publish
+        MNW_STAMP(1)      // reductions + records folded + barrier + publish
 
-        // ---- floats -> pixel indices (descriptor independent), all waves ------------------------------
-        const float low = jb.low, dx = jb.dxq;
-        const double rdx = jb.rdx;
-        bool tiny = false;
-        if (full) {
+        if (have_prev) {
+            // ---- 3. item i-1: descriptor of its block (wave 0) while the others quantize ----------------
+            if (wave_id() == 0) {
+                uint32_t v0 = swv[0][0], v1 = swv[1][0], v2 = swv[2][0], v3 = swv[3][0], fl = swf[0];
 #pragma unroll
-            for (int k = 0; k < kV; ++k) {
+                for (int w = 1; w < kW; ++w) {
+                    v0 = max(v0, swv[0][w]); v1 = max(v1, swv[1][w]); v2 = max(v2, swv[2][w]); v3 = max(v3, swv[3][w]);
+                    fl |= swf[w];
+                }
+                uint64_t g;
+                if (__builtin_expect(fl & 1u, 0)) {
+#ifdef MNW_STAMPS
+                    if (lane_id() == 0) atomicAdd(&g_slow_sweeps, 1ull);
+#endif
+                    g = sweep_block_f32(jobs, pj, recs, gen, abort_flag, abort_host, meta, pit == pjb.tile0);
+                } else {
+                    g = desc_from_sweep_f32(pjb, pj, v0, v1, v2, v3, (fl & 2u) != 0, meta, pit == pjb.tile0);
+                }
+                if (lane_id() == 0) shared_slot = g;
+            }
+            const float low = pjb.low, dx = pjb.dxq;
+            const double rdx = pjb.rdx;
+            uint32_t q[kGroup];
+            bool tiny = false;
+#pragma unroll
+            for (int k = 0; k < kGroup / 4; ++k) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float rq = quant_mul(__uint_as_float(e[k][c]), low, rdx);
-                    tiny |= quant_tiny(rq);
-                    e[k][c] = (uint32_t)(int32_t)floorf(rq);
+                    const float rq = quant_mul(__uint_as_float(r[c]), low, rdx);
+                    tiny |= __builtin_amdgcn_classf(rq, 0x90);             // a subnormal quotient (quant_tiny)
+                    q[4 * k + c] = (uint32_t)cvt_floor_i32(rq);
                 }
             }
-        }
-        MNW_STAMP(2)      // convert
-
-        // ---- the block's descriptor: wave 0 sweeps the records, everybody else waits at the barrier ---
-        if (wave_id() == 0) {
-            const uint64_t g = sweep_block_f32(jobs, j, recs, gen, abort_flag, meta, it == jb.tile0);
-            if (lane_id() == 0) shared_slot = g;
-        }
-        __syncthreads();
-        const uint64_t gran = shared_slot;
-        __syncthreads();
-        MNW_STAMP(3)      // sweep (wave 0) + barrier
-        if (!(gran & kGranReady)) return;                  // aborted
-        const Desc d = gran_decode(gran, jb.n);
-        const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
-        if (!ok) { load_next(); continue; }
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
-        const int32_t pmin = (int32_t)d.pmin;
-        const uint32_t imin = (uint32_t)(int32_t)d.imin, pix = (uint32_t)jb.pixels;
-        const bool per = jb.periodic == 1;
-        const int redo = __any(tiny);                  // a quotient below the float32 normal range: IEEE division
-
-        // ---- re-base, stage, pack, store: one 16,384-element tile ------------------------------------
-        if (full) {
-#pragma unroll
-            for (int k = 0; k < kV; ++k) {
-                u32x4 r;
-                if (__builtin_expect(redo, 0)) {
-                    // a tiny quotient somewhere in this wave: redo this lane's own elements with the
-                    // IEEE division (the floats are reloaded: the registers hold indices by now)
-                    const f32x4 xv = ldg<f32x4>(x + base + 4 * (k * kThreadsR + tid));
-                    for (int c = 0; c < 4; ++c) e[k][c] = (uint32_t)(int32_t)quant_floor(xv[c], low, dx);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    uint32_t uq = e[k][c];
-                    if (per && (int32_t)uq < pmin) uq += pix;          // bound(), group.go:374-382
-                    r[c] = uq - imin;                                  // group.go:247
-                }
-                *reinterpret_cast<u32x4*>(lds + stage32_idx(4 * (k * kThreadsR + tid))) = r;
+            if (__builtin_expect(tiny, 0)) {
+                // a quotient below the float32 normal range: this lane redoes its group with the IEEE division
+#pragma unroll 1
+                for (int i = 0; i < kGroup; ++i)
+                    q[i] = (uint32_t)(int32_t)quant_floor(__uint_as_float(lds[tid * kStride32 + i]), low, dx);
             }
-        } else {
-            for (int i = tid; i < kItem; i += kThreadsR) {
-                uint32_t r = 0;
-                if (base + i < jb.n) {
-                    const int32_t qq = (int32_t)quant_floor(ldg<float>(x + base + i), low, dx);
-                    uint32_t uq = (uint32_t)qq;
-                    if (per && qq < pmin) uq += pix;
-                    r = uq - imin;
-                }
-                lds[stage32_idx(i)] = r;
-            }
-        }
-        load_next();         // the values are staged: the next item goes into the same registers
-        lds_barrier();
-        uint32_t g[kGroup];
+            lds_barrier();                                     // floats consumed; descriptor visible
+            const uint64_t gran = shared_slot;
+            MNW_STAMP(2)      // descriptor (wave 0) / quantize + barrier
+            if (!(gran & kGranReady)) break;                   // aborted (uniform: every wave sees the same word)
+            const Desc d = gran_decode(gran, pjb.n);
+            const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0);
+            if (ok) {
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
+                const uint32_t imin = (uint32_t)(int32_t)d.imin;
+                // bound() (group.go:374-382) then the subtraction of the block minimum (group.go:247):
+                // with r = q - imin (mod 2^32) the values below the ring start are exactly those whose r
+                // "went negative", and r + pixels brings precisely them back under every other r
+                const uint32_t wrap = (pjb.periodic == 1 && d.pmin == d.imin) ? (uint32_t)pjb.pixels : 0u;
 #pragma unroll
-        for (int k = 0; k < kGroup / 4; ++k) {
-            const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
-            g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
+                for (int i = 0; i < kGroup; ++i) {
+                    const uint32_t r = q[i] - imin;
+                    q[i] = min(r, r + wrap);
+                }
+                if (pbase + kItem > pjb.n) {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i)
+                        if (pbase + kGroup * tid + i >= pjb.n) q[i] = 0;
+                }
+                pack_group32_switch(q, b, lds + tid * b);
+                lds_barrier();
+                MNW_STAMP(3)      // re-base + pack + barrier
+                const int64_t tile_byte0 = pbase / 8 * b;
+                int64_t tile_bytes = (int64_t)kItem / 8 * b;
+                if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes);
+            }
+            lds_barrier();                                     // the LDS buffer is free again
+            MNW_STAMP(4)      // stores issued + barrier
         }
-        lds_barrier();
-        pack_group32(g, b, lds + tid * b);
-        lds_barrier();
-        const int64_t tile_byte0 = base / 8 * b;
-        int64_t tile_bytes = (int64_t)kItem / 8 * b;
-        if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-        store_tile<kThreadsR>(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
-        lds_barrier();
-        MNW_STAMP(4)      // stage + pack + store
+        // ---- 4. park item i, start item i+1 ------------------------------------------------------------
+        if (have_cur) {
+            if (srem >= kItem) {
+                uint32_t* const park = lds + stage32_idx(4 * tid);      // + k * 1152 dwords: 4*(k*256+tid) -> stage index
+#pragma unroll
+                for (int k = 0; k < kV; ++k)
+                    *reinterpret_cast<u32x4*>(park + k * (4 * kThreadsR / kGroup * kStride32)) = e[k];
+            } else {
+#pragma unroll 1
+                for (int i = tid; i < kItem; i += kThreadsR)
+                    lds[stage32_idx(i)] = i < (int)srem ? ldg<uint32_t>(sx + i) : 0u;
+            }
+            if (have_next) issue();
+            MNW_STAMP(5)      // park + next loads issued
+        }
+        have_prev = have_cur;
+        pj = sj; pbase = sbase; pit = sit;
+        it = nit;
+        have_cur = have_next;
     }
     MNW_STAMP_FLUSH
 }
@@ -1532,9 +1696,12 @@ __global__ __launch_bounds__(kThreads) void k_bound_i64(int64_t* __restrict__ q,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                       int64_t copy_words, uint32_t* __restrict__ zero0, int64_t zero0_words,
-                                                      uint32_t* __restrict__ zero1, int64_t zero1_words) {
+                                                      uint32_t* __restrict__ zero1, int64_t zero1_words,
+                                                      const uint32_t* __restrict__ src2, uint32_t* __restrict__ dst2,
+                                                      int64_t copy2_words) {
     const int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x, step = (int64_t)gridDim.x * kThreads;
     for (int64_t i = i0; i < copy_words; i += step) dst[i] = src[i];
+    for (int64_t i = i0; i < copy2_words; i += step) dst2[i] = src2[i];
     for (int64_t i = i0; i < zero0_words; i += step) zero0[i] = 0;
     for (int64_t i = i0; i < zero1_words; i += step) zero1[i] = 0;
 }
@@ -1543,13 +1710,14 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict
 // launch wrappers (called from mnw_api.cpp)
 // ------------------------------------------------------------------------------------------------
 void launch_prepare(hipStream_t s, const void* src, void* dst, int64_t copy_bytes, void* zero0, int64_t zero0_bytes,
-                    void* zero1, int64_t zero1_bytes) {
-    const int64_t words = (copy_bytes + zero0_bytes + zero1_bytes) / 4;
+                    void* zero1, int64_t zero1_bytes, const void* src2, void* dst2, int64_t copy2_bytes) {
+    const int64_t words = (copy_bytes + copy2_bytes + zero0_bytes + zero1_bytes) / 4;
     int grid = (int)((words + kThreads * 4 - 1) / (kThreads * 4));
     if (grid < 1) grid = 1;
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(k_prepare, dim3(grid), dim3(kThreads), 0, s, (const uint32_t*)src, (uint32_t*)dst, copy_bytes / 4,
-                       (uint32_t*)zero0, zero0_bytes / 4, (uint32_t*)zero1, zero1_bytes / 4);
+                       (uint32_t*)zero0, zero0_bytes / 4, (uint32_t*)zero1, zero1_bytes / 4,
+                       (const uint32_t*)src2, (uint32_t*)dst2, copy2_bytes / 4);
 }
 void launch_reduce_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, uint64_t* stats, void* sync, Meta* meta) {
     hipLaunchKernelGGL(k_reduce_f32, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, (JobSync*)sync, meta);
@@ -1566,11 +1734,13 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, Meta* meta) {
-    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag, meta);
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta) {
+    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag,
+                       abort_host, meta);
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }
+int64_t reg_item_elems() { return kItem; }
 int encode_reg_f32_blocks_per_cu() {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32, kThreadsR, 0) != hipSuccess) return 0;

@@ -37,20 +37,22 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(dj, hj.data(), sizeof(DevJob) * nj, hipMemcpyHostToDevice)); CHK(hipMemset(recs, 0, sizeof(ItemRec) * items)); CHK(hipMemset(ab, 0, 128));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     uint32_t gen = 1;
-    for (int r = 0; r < 3; ++r) launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, dm);
+    for (int r = 0; r < 3; ++r) launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm);
     CHK(hipDeviceSynchronize()); CHK(hipMemset(sb, 0, 8 * 8 * 4096));
-    CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, dm); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+    CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
     float ms; CHK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> h(8 * grid); CHK(hipMemcpy(h.data(), sb, 8 * 8 * grid, hipMemcpyDeviceToHost));
     Meta m0; CHK(hipMemcpy(&m0, dm, sizeof m0, hipMemcpyDeviceToHost)); uint32_t abv; CHK(hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost));
-    const char* names[5] = {"lookup+loads+lane stats", "wg reduce+publish", "convert", "sweep+barrier", "two pack tiles"};
+    const char* names[6] = {"loads wait+lane stats", "reduce+fold+barrier+publish", "descriptor|quantize+barrier", "rebase+pack+barrier", "store+barrier", "park+issue next"};
     double cyc = 0, rt = 0; for (int w = 0; w < grid; ++w) { cyc += h[w * 8 + 6]; rt += h[w * 8 + 7]; }
     const double ghz = cyc / rt * 0.1;
     printf("n=%ld block=%ld items=%ld grid=%d items/WG=%.1f kernel %.1f us (stamped build) bits=%ld abort=%u\n", n, B, items, grid, (double)items / grid, ms * 1e3, (long)m0.bits, abv);
     printf("  workgroup lifetime mean %.2f us, shader clock %.2f GHz\n", rt / grid / 100.0, ghz);
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < 6; ++i) {
         double s2 = 0; for (int w = 0; w < grid; ++w) s2 += h[w * 8 + i];
         printf("  %-26s %.2f us per WG = %.2f us per item\n", names[i], s2 / grid / ghz / 1e3, s2 / grid / ghz / 1e3 / ((double)items / grid));
     }
+    unsigned long long slow = 0; CHK(hipMemcpyFromSymbol(&slow, HIP_SYMBOL(g_slow_sweeps), sizeof slow));
+    printf("  slow-path sweeps (all launches) %llu of %ld items per launch\n", slow, items);
     return 0;
 }
