@@ -13,6 +13,12 @@ INT_GROUP = 10     # go/group.go:22
 FLOAT_GROUP = 11   # go/group.go:23
 
 
+_META_DTYPE = [("min", "<i8"), ("bits", "<i8"), ("nbytes", "<i8"), ("status", "<i8")]
+_DEC_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("n", "<i8"), ("src_len", "<i8"), ("min", "<i8"), ("bits", "<i8"),
+              ("pixels", "<i8"), ("low", "<f4"), ("high", "<f4"), ("kind", "<i4"), ("periodic", "<i4"),
+              ("seed", "<u8"), ("block", "<u8")]
+
+
 @dataclass
 class EncJob:
     """One block to encode: what Writer.Data hands to group.writeData (writer.go:90-103)."""
@@ -124,15 +130,33 @@ class Context:
     def _count(jobs):
         return jobs._n if isinstance(jobs, C.Array) else len(jobs)
 
-    def encode_blocks(self, jobs, stream=None, check=True):
+    def encode_blocks(self, jobs, stream=None, check=True, raw=False):
+        """raw=True returns the C array of mnw_block_meta itself (see `metas_of`, `dec_batch_update`): a
+        caller that runs many small blocks per call avoids one Python object per block that way."""
         arr = self._enc_array(jobs)
         n = self._count(arr)
         meta = (BlockMetaC * max(n, 1))()
+        meta._n = n
         rc = self._L.mnw_encode_blocks(self._h, stream, arr, n, meta)
-        out = [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[:n]]
         if check:
             self._check(rc)
-        return out
+        return meta if raw else self.metas_of(meta)
+
+    @staticmethod
+    def metas_of(meta):
+        return [BlockMeta(m.min, m.bits, m.nbytes, m.status) for m in meta[:meta._n]]
+
+    @staticmethod
+    def dec_batch_update(arr, meta):
+        """Copy (min, bits, nbytes) of a raw meta array into the matching jobs of a prebuilt decode batch:
+        what a reader does with intGroup.mins/bits and the block index (group.go:257-263), vectorised."""
+        import numpy as np
+        n = arr._n
+        d = np.frombuffer(arr, dtype=_DEC_DTYPE, count=n)
+        m = np.frombuffer(meta, dtype=_META_DTYPE, count=n)
+        d["min"] = m["min"]
+        d["bits"] = m["bits"]
+        d["src_len"] = m["nbytes"]
 
     def encode_blocks_async(self, jobs, stream=None):
         arr = self._enc_array(jobs)

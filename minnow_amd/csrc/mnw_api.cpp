@@ -109,7 +109,7 @@ struct mnw_ctx {
     int64_t group_bytes = 1ll << 40;   // two-kernel path: all blocks of a batch in one reduce + one pack launch
     int grid_cap = 0;
     int fused = 0;               // float encode as one persistent launch per batch (k_encode_f32): opt-in, see DESIGN.md
-    int single_read = 0;         // float encode through k_encode_reg_f32 (block read once): opt-in, see DESIGN.md
+    int single_read = 1;         // float encode through k_encode_reg_f32 (block read once) whenever the batch is eligible
     int reg_blocks_per_cu = 0;   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
     void* d_recs = nullptr;      // single read: one published statistics record per item (grow-only)

@@ -637,12 +637,13 @@ __device__ __forceinline__ float quant_mul(float x, float low, double rdx) {
 // Diagnostic builds only (-DMNW_STAMPS, tools/microbench): per-phase cycle sums of wave 0 of every
 // workgroup, written to a buffer no other code reads.  The shipped library has no stamps.
 #ifdef MNW_STAMPS
+__device__ unsigned long long* g_stamp_abs = nullptr;
 __device__ unsigned long long* g_stamp_buf = nullptr;
 __device__ int g_dbg_skip = 0;
 #define MNW_STAMP_DECL unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
 #define MNW_STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define MNW_STAMP(i) { unsigned long long t2_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc[i] += t2_ - st_t; st_t = t2_; }
-#define MNW_STAMP_FLUSH if (g_stamp_buf && threadIdx.x == 0) { st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_rt0; st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0; for (int i_ = 0; i_ < 8; ++i_) g_stamp_buf[blockIdx.x * 8 + i_] += st_acc[i_]; }
+#define MNW_STAMP_FLUSH if (g_stamp_buf && threadIdx.x == 0) { const unsigned long long e_ = __builtin_amdgcn_s_memrealtime(); st_acc[7] = e_ - st_rt0; st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0; for (int i_ = 0; i_ < 8; ++i_) g_stamp_buf[blockIdx.x * 8 + i_] += st_acc[i_]; if (g_stamp_abs) { g_stamp_abs[blockIdx.x * 2] = st_rt0; g_stamp_abs[blockIdx.x * 2 + 1] = e_; } }
 #else
 #define MNW_STAMP_DECL
 #define MNW_STAMP_START
@@ -1034,7 +1035,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                                                                  int64_t total_items, const int* __restrict__ item_job,
                                                                  ItemRec* __restrict__ recs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
-                                                                 uint32_t* __restrict__ abort_host, Meta* __restrict__ meta) {
+                                                                 uint32_t* __restrict__ abort_host,
+                                                                 Meta* __restrict__ meta) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufR];
     __shared__ float red[4][kThreadsR / 64];
     __shared__ int redbad[kThreadsR / 64];
@@ -1085,6 +1087,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         const float xh = cxh;
         const float* const sx = cx + cbase;
         const int64_t srem = cn - cbase;                 // elements of item i (>= kItem: a full one)
+        // The next item.  (Handing the items out with a counter instead would even out the workgroups -- the
+        // hardware favours the oldest waves of a CU, so the youngest workgroups finish ~40% after the oldest
+        // -- but the returning atomic sits on wave 0's path every trip and measured 15% slower overall.)
         const int64_t nit = it + gridDim.x;
         const bool have_next = have_cur && nit < total_items;
         // where the next item lives: scalar loads, started long before they are needed
@@ -1203,6 +1208,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                     fl |= swf[w];
                 }
                 uint64_t g;
+#ifdef MNW_DIAG_NOWAIT
+                fl &= ~1u;                           // diagnostic build: never wait for a record (output is then wrong)
+#endif
                 if (__builtin_expect(fl & 1u, 0)) {
 #ifdef MNW_STAMPS
                     if (lane_id() == 0) atomicAdd(&g_slow_sweeps, 1ull);

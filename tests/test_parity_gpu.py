@@ -451,15 +451,19 @@ def test_c2_full_size_properties(mnw, ctx, oracle, torch_mod):
 
 
 # ------------------------------------------------------------------------------------------------
-# the opt-in encode structures must produce the same bytes as the default one
+# every float-encode structure must produce the reference's bytes: the single-read kernel (default for
+# batches whose blocks fit on chip), the reduce + pack pair (large blocks, or single_read=0) and the
+# opt-in fused launch
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", ["fused", "single_read"])
-def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
+@pytest.mark.parametrize("mode", ["single_read", "two_pass", "fused"])
+def test_encode_structures_bit_exact(mnw, oracle, torch_mod, mode):
     torch = torch_mod
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(21)
     low, high, pixels = 0.0, 250.0, 250000
-    sizes = [1, 63, 8191, 8192, 8193, 16384, 16385, 40000, 100001, 300000, 2**20 + 17, 5 * 2**20]
+    sizes = [1, 63, 8191, 8192, 8193, 16384, 16385, 40000, 100001, 300000, 2**20 + 17, 2**21 + 5]
+    if mode != "single_read":
+        sizes.append(5 * 2**20)                 # more items than the single-read kernel takes: two-pass anyway
     xs = []
     for k, n in enumerate(sizes):
         c, sg = [(125.0, 20.0), (0.2, 0.4), (249.8, 0.5), (60.0, 0.01)][k % 4]
@@ -469,14 +473,21 @@ def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
     xs.append(np.full(70000, 25.0, dtype=np.float32))                      # constant block: bits == 0
     bad = np.mod(125 + 5 * rng.standard_normal(50000), 250).astype(np.float32); bad[777] = np.nan
     xs.append(bad)                                                         # exact path inside a batch
+    tiny = np.mod(125 + 5 * rng.standard_normal(20000), 250).astype(np.float32); tiny[5] = np.float32(1e-42)
+    xs.append(tiny)                                                        # subnormal quotient: IEEE-division redo
     with mnw.Context(0) as c2:
-        c2.set_option(mode, 1)
+        if mode == "fused":
+            c2.set_option("fused", 1)
+        elif mode == "two_pass":
+            c2.set_option("single_read", 0)
         c2.set_option("group_bytes", 3 << 20)      # several groups for the fused form
         ts = [torch.from_numpy(x).to(dev) for x in xs]
         outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]   # the NaN block needs 64 bits
         jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
                 for t, o in zip(ts, outs)]
         torch.cuda.synchronize()
+        c2.timing_enable(True)
+        c2.timing_reset()
         for rep in range(3):                        # slots are reused: stale sync words would show up here
             metas = c2.encode_blocks(jobs)
             torch.cuda.synchronize()
@@ -484,6 +495,38 @@ def test_alternative_encode_modes_bit_exact(mnw, oracle, torch_mod, mode):
                 omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
                 assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
                 assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        # the structure under test is the one that ran
+        kt = c2.timing_get()
+        ran = {k for k, v in kt.items() if v["launches"]}
+        want = {"single_read": "k_encode_reg_f32", "two_pass": "k_pack_f32", "fused": "k_encode_f32"}[mode]
+        assert want in ran, (mode, sorted(ran))
+        if mode == "single_read":
+            assert "k_reduce_f32" not in ran or kt["k_reduce_f32"]["launches"] <= 3   # only the exact-path reruns
+
+
+def test_single_read_falls_back_for_large_blocks(mnw, oracle, torch_mod):
+    """A batch with a block of more items than the single-read kernel may hold on chip takes the two-pass
+    path as a whole (same bytes either way)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(22)
+    low, high, pixels = 0.0, 250.0, 250000
+    xs = [np.mod(125 + 20 * rng.standard_normal(n), 250.0).astype(np.float32) for n in (2**22 + 8192 + 3, 5000)]
+    with mnw.Context(0) as c2:
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(4 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
+                for t, o in zip(ts, outs)]
+        torch.cuda.synchronize()
+        c2.timing_enable(True)
+        metas = c2.encode_blocks(jobs)
+        torch.cuda.synchronize()
+        kt = c2.timing_get()
+        assert kt["k_pack_f32"]["launches"] >= 1 and not kt.get("k_encode_reg_f32", {"launches": 0})["launches"]
+        for x, m, o in zip(xs, metas, outs):
+            omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+            assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
 
 
 # ------------------------------------------------------------------------------------------------
