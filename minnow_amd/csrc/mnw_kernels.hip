@@ -593,16 +593,25 @@ __device__ __forceinline__ void pack_group64_lds(const uint32_t* __restrict__ in
 // the block's last tile byte-wise (ArrayBytes is a byte count, bit.go:23-25; pad bits are zero)
 template <int NT = kThreads>
 __device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out, uint8_t* __restrict__ dst,
-                                           int64_t tile_byte0, int64_t tile_bytes) {
+                                           int64_t tile_byte0, int64_t tile_bytes, int tid = threadIdx.x) {
     const int full = (int)(tile_bytes >> 4);
-    for (int c = threadIdx.x; c < full; c += NT)
+    for (int c = tid; c < full; c += NT)
         stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(lds_out + 4 * c));
     const int rem = (int)(tile_bytes & 15);
-    if ((int)threadIdx.x < rem) {
-        const int k = threadIdx.x;
+    if (tid < rem) {
+        const int k = tid;
         const uint32_t w = lds_out[4 * full + (k >> 2)];
         stg<uint8_t>(dst + tile_byte0 + 16 * (int64_t)full + k, (uint8_t)(w >> (8 * (k & 3))));
     }
+}
+
+// the lane's index in the workgroup as a value the compiler cannot see through: address arithmetic built
+// on it inside a loop is redone there (two or three instructions) instead of being hoisted out of the loop
+// and kept -- or, once registers run out, spilled -- across the whole trip
+__device__ __forceinline__ int opaque_tid() {
+    int t;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"((int)threadIdx.x));
+    return t;
 }
 
 // true for a NONZERO quotient below the float32 normal range, where the float64-multiply argument does
@@ -1066,10 +1075,11 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         // (a block's last, partial item is not held in registers: its statistics and its parked copy are
         // made by plain loops over global memory, see below)
         if (cbase + kItem <= cn) {
+            const int t = opaque_tid();
 #pragma unroll
             for (int k = 0; k < kV; ++k) {
                 const float* pk = cx + cbase + k * (4 * kThreadsR);     // wave-uniform part of the address
-                e[k] = ldg<u32x4>(pk + 4 * tid);
+                e[k] = ldg<u32x4>(pk + 4 * t);
             }
         }
     };
@@ -1095,11 +1105,12 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         // where the next item lives: scalar loads, started long before they are needed
         if (have_next) locate(nit);
 
-        // ---- 1. the records of item i-1's block, one per lane (two for blocks of more than 256 items).
-        // Issued ahead of everything else of the trip that touches memory, used after the statistics.
+        // ---- 1. the records of item i-1's block, one per lane (blocks of more than 256 items: the second
+        // half follows once the first is folded).  Issued ahead of everything else of the trip that touches
+        // memory, used after the statistics.
         DevJob pjb;
         int pitems = 0;
-        uint64_t sw[2][4];
+        uint64_t sw[4];
         if (have_prev) {
             pjb = jobs[pj];
             pitems = (int)items_of(pjb.n);
@@ -1107,13 +1118,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             const uint64_t neutral = (uint64_t)gen << 32;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                sw[0][k] = tid < pitems ? __hip_atomic_load(&r0[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
-            if (pitems > kThreadsR) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    sw[1][k] = tid + kThreadsR < pitems
-                                   ? __hip_atomic_load(&r0[tid + kThreadsR].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
-            }
+                sw[k] = tid < pitems ? __hip_atomic_load(&r0[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
         }
 
         if (have_cur) {
@@ -1156,17 +1161,22 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             // fold what the record loads brought
             uint32_t v[4] = {0, 0, 0, 0};
             uint32_t bad = 0, missing = 0;
-#pragma unroll
+#pragma unroll 1
             for (int h = 0; h < 2; ++h) {
-                if (h == 1 && pitems <= kThreadsR) break;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t tag = (uint32_t)(sw[h][k] >> 32);
+                    const uint32_t tag = (uint32_t)(sw[k] >> 32);
                     missing |= (tag & ~kRecBad) != gen;
                     bad |= tag & kRecBad;
-                    const uint32_t val = (uint32_t)sw[h][k];
+                    const uint32_t val = (uint32_t)sw[k];
                     v[k] = val > v[k] ? val : v[k];
                 }
+                if (h == 1 || pitems <= kThreadsR) break;
+                const ItemRec* r1 = recs + pjb.tile0 + kThreadsR;
+                const uint64_t neutral = (uint64_t)gen << 32;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    sw[k] = tid + kThreadsR < pitems ? __hip_atomic_load(&r1[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(v[k]);
@@ -1225,14 +1235,30 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             const double rdx = pjb.rdx;
             uint32_t q[kGroup];
             bool tiny = false;
+            if (low == 0.0f) {
+                // x - 0 == x exactly (go/group.go:318 with low == 0): one instruction less per element
 #pragma unroll
-            for (int k = 0; k < kGroup / 4; ++k) {
-                const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+                for (int k = 0; k < kGroup / 4; ++k) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float rq = quant_mul(__uint_as_float(r[c]), low, rdx);
-                    tiny |= __builtin_amdgcn_classf(rq, 0x90);             // a subnormal quotient (quant_tiny)
-                    q[4 * k + c] = (uint32_t)cvt_floor_i32(rq);
+                    for (int c = 0; c < 4; ++c) {
+                        const float rq = (float)__dmul_rn((double)__uint_as_float(r[c]), rdx);
+                        tiny |= __builtin_amdgcn_classf(rq, 0x90);         // a subnormal quotient (quant_tiny)
+                        q[4 * k + c] = (uint32_t)cvt_floor_i32(rq);
+                    }
+                    if (k & 1) __builtin_amdgcn_sched_barrier(0);      // at most two LDS reads ahead: bounds the live registers
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kGroup / 4; ++k) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(lds + tid * kStride32 + 4 * k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float rq = quant_mul(__uint_as_float(r[c]), low, rdx);
+                        tiny |= __builtin_amdgcn_classf(rq, 0x90);
+                        q[4 * k + c] = (uint32_t)cvt_floor_i32(rq);
+                    }
+                    if (k & 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (__builtin_expect(tiny, 0)) {
@@ -1254,15 +1280,21 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                 // with r = q - imin (mod 2^32) the values below the ring start are exactly those whose r
                 // "went negative", and r + pixels brings precisely them back under every other r
                 const uint32_t wrap = (pjb.periodic == 1 && d.pmin == d.imin) ? (uint32_t)pjb.pixels : 0u;
+                if (wrap == 0) {
 #pragma unroll
-                for (int i = 0; i < kGroup; ++i) {
-                    const uint32_t r = q[i] - imin;
-                    q[i] = min(r, r + wrap);
+                    for (int i = 0; i < kGroup; ++i) q[i] -= imin;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) {
+                        const uint32_t r = q[i] - imin;
+                        q[i] = min(r, r + wrap);
+                    }
                 }
                 if (pbase + kItem > pjb.n) {
+                    const int64_t e0 = pbase + kGroup * opaque_tid();
 #pragma unroll
                     for (int i = 0; i < kGroup; ++i)
-                        if (pbase + kGroup * tid + i >= pjb.n) q[i] = 0;
+                        if (e0 + i >= pjb.n) q[i] = 0;
                 }
                 pack_group32_switch(q, b, lds + tid * b);
                 lds_barrier();
@@ -1270,7 +1302,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                 const int64_t tile_byte0 = pbase / 8 * b;
                 int64_t tile_bytes = (int64_t)kItem / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes);
+                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid());
             }
             lds_barrier();                                     // the LDS buffer is free again
             MNW_STAMP(4)      // stores issued + barrier
@@ -1278,7 +1310,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         // ---- 4. park item i, start item i+1 ------------------------------------------------------------
         if (have_cur) {
             if (srem >= kItem) {
-                uint32_t* const park = lds + stage32_idx(4 * tid);      // + k * 1152 dwords: 4*(k*256+tid) -> stage index
+                uint32_t* const park = lds + stage32_idx(4 * opaque_tid());   // + k * 1152 dwords: 4*(k*256+tid) -> stage index
 #pragma unroll
                 for (int k = 0; k < kV; ++k)
                     *reinterpret_cast<u32x4*>(park + k * (4 * kThreadsR / kGroup * kStride32)) = e[k];
