@@ -71,6 +71,11 @@ struct JobSlot {
     int* h_itemjob = nullptr;
     int* d_itemjob = nullptr;
     size_t cap_itemjob = 0;
+    // What the device copy of the tables holds, if it was uploaded by a path that can reuse it (decode,
+    // single-read encode): a batch with byte-identical tables -- a pipeline that cycles through the same
+    // buffers -- skips the k_prepare launch (~7 us: it reads pinned host memory across the link).
+    std::vector<uint8_t> shadow;
+    int shadow_tag = 0;           // 0: nothing reusable, 1: decode tables, 2: single-read encode tables
     hipEvent_t consumed = nullptr;
     bool in_flight = false;
 };
@@ -85,7 +90,8 @@ struct mnw_ctx {
     // slots so that a batch can be prepared while the kernels of earlier batches still read theirs;
     // a slot is reused only after the event recorded behind its last consumer has completed.
     JobSlot slots[kSlots];
-    int cur = 0;
+    JobSlot dslots[kSlots];       // decode batches cycle through their own ring (their tables repeat among themselves)
+    int cur = 0, dcur = 0;
     JobSlot* pend = nullptr;      // slot of the pending async encode batch
 
     // staging for the host-pointer entry points
@@ -152,14 +158,17 @@ void free_slot(JobSlot& sl) {
     sl.d_up = nullptr; sl.d_jobs = nullptr; sl.cap = 0;
     if (sl.d_itemjob) { hipFree(sl.d_itemjob); hipHostFree(sl.h_itemjob); }
     sl.d_itemjob = nullptr; sl.h_itemjob = nullptr; sl.cap_itemjob = 0;
+    sl.shadow_tag = 0;
 }
 
 // next ring slot with room for n jobs; waits (host side) only if that slot's previous batch is
 // still being consumed by the GPU
-int acquire_slot(mnw_ctx* c, int n, JobSlot** out) {
-    c->cur = (c->cur + 1) % kSlots;
-    JobSlot& sl = c->slots[c->cur];
-    if (&sl == c->pend) { c->cur = (c->cur + 1) % kSlots; return acquire_slot(c, n, out); }
+int acquire_slot(mnw_ctx* c, int n, JobSlot** out, bool decode_ring = false) {
+    int& cur = decode_ring ? c->dcur : c->cur;
+    JobSlot* ring = decode_ring ? c->dslots : c->slots;
+    cur = (cur + 1) % kSlots;
+    JobSlot& sl = ring[cur];
+    if (&sl == c->pend) { cur = (cur + 1) % kSlots; return acquire_slot(c, n, out, decode_ring); }
     if (!sl.consumed) HIPCHK(c, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
     if (sl.in_flight) { HIPCHK(c, hipEventSynchronize(sl.consumed)); sl.in_flight = false; }
     if (n > sl.cap) {
@@ -197,7 +206,16 @@ void* sync_ptr(JobSlot* sl, int j) { return sl->d_sync + sizeof(uint32_t) * kSyn
 
 // One small launch sets a batch up: job records (and group tables) from pinned host memory into
 // device memory, statistics and synchronisation words of the first njobs jobs zeroed.
+bool tables_unchanged(const JobSlot* sl, int tag, size_t bytes) {
+    return sl->shadow_tag == tag && sl->shadow.size() == bytes && memcmp(sl->shadow.data(), sl->h_up, bytes) == 0;
+}
+void remember_tables(JobSlot* sl, int tag, size_t bytes) {
+    sl->shadow.assign(sl->h_up, sl->h_up + bytes);
+    sl->shadow_tag = tag;
+}
+
 int prepare_slot(mnw_ctx* c, JobSlot* sl, hipStream_t s, int njobs, bool zero) {
+    sl->shadow_tag = 0;
     mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
                         zero ? sl->d_stats : nullptr, zero ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * njobs) : 0,
                         zero ? sl->d_sync : nullptr, zero ? (int64_t)(sizeof(uint32_t) * kSyncPad + sl->sync_stride * njobs) : 0);
@@ -427,23 +445,28 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         HIPCHK(c, hipMalloc((void**)&sl->d_itemjob, want * sizeof(int)));
         HIPCHK(c, hipHostMalloc((void**)&sl->h_itemjob, want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
         sl->cap_itemjob = want;
-    }
-    for (int k = 0; k < nfloat; ++k) {
-        const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
-        for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k;
+        sl->shadow_tag = 0;                   // a fresh device table: nothing to reuse
     }
     c->reg_gen = (c->reg_gen + 1) & 0x7fffffffu;
     if (c->reg_gen == 0) c->reg_gen = 1;
     sl->h_sync[0] = 0;                        // the kernel raises it (pinned host word) if it gives up
-    // one small launch: job records and item table to device memory, abort word zeroed
     // (int jobs of the same batch, slots [nfloat, nslot_all), go through the two-kernel path afterwards and need
     // their statistics and synchronisation words zeroed; the float jobs here need neither)
     const bool ints = nslot_all > nfloat;
-    mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
-                        ints ? sl->d_stats : nullptr, ints ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot_all) : 0,
-                        sl->d_sync, (int64_t)(sizeof(uint32_t) * kSyncPad + (ints ? sl->sync_stride * nslot_all : 0)),
-                        sl->h_itemjob, sl->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16);
-    HIPCHK(c, hipGetLastError());
+    const size_t table_bytes = sizeof(DevJob) * (size_t)nfloat;
+    if (ints || !tables_unchanged(sl, 2, table_bytes)) {
+        for (int k = 0; k < nfloat; ++k) {
+            const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
+            for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k;
+        }
+        // one small launch: job records and item table to device memory, abort word zeroed
+        mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
+                            ints ? sl->d_stats : nullptr, ints ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot_all) : 0,
+                            sl->d_sync, (int64_t)(sizeof(uint32_t) * kSyncPad + (ints ? sl->sync_stride * nslot_all : 0)),
+                            sl->h_itemjob, sl->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16);
+        HIPCHK(c, hipGetLastError());
+        if (ints) sl->shadow_tag = 0; else remember_tables(sl, 2, table_bytes);
+    }
     if (items > 0) {
         if (items < grid) grid = (int)items;
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
@@ -578,6 +601,7 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     for (auto& t : c->launches) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (auto& sl : c->slots) { free_slot(sl); if (sl.consumed) hipEventDestroy(sl.consumed); }
+    for (auto& sl : c->dslots) { free_slot(sl); if (sl.consumed) hipEventDestroy(sl.consumed); }
     if (c->d_in) hipFree(c->d_in);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_q) hipFree(c->d_q);
@@ -750,6 +774,7 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
         // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
         // part of the GPU): rerun the float jobs through the two-kernel path.  Still the GPU path.
         c->fused_aborts++;
+        sl->shadow_tag = 0;                       // the abort word on the device is set: the next batch must prepare
         for (int k = 0, g0 = 0; g0 < c->pend_nfloat; ) {   // group-relative tile numbering again
             (void)k;
             int g1 = g0; int64_t bytes = 0, tiles = 0;
@@ -797,7 +822,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     JobSlot* sl;
-    int rc = acquire_slot(c, njobs > 0 ? njobs : 1, &sl);
+    int rc = acquire_slot(c, njobs > 0 ? njobs : 1, &sl, true);
     if (rc) return rc;
     // three launch classes: float 32-bit path, float 64-bit path, int64
     int cls_begin[4] = {0, 0, 0, 0};
@@ -833,8 +858,12 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     }
     cls_begin[3] = nslot;
     if (nslot == 0) return MNW_OK;
-    rc = prepare_slot(c, sl, s, nslot, false);
-    if (rc) return rc;
+    const size_t table_bytes = sizeof(DevJob) * (size_t)nslot;
+    if (!tables_unchanged(sl, 1, table_bytes)) {
+        rc = prepare_slot(c, sl, s, nslot, false);
+        if (rc) return rc;
+        remember_tables(sl, 1, table_bytes);
+    }
     for (int cls = 0; cls < 3; ++cls) {
         const int j0 = cls_begin[cls], j1 = cls_begin[cls + 1];
         if (j1 == j0) continue;

@@ -529,6 +529,49 @@ def test_single_read_falls_back_for_large_blocks(mnw, oracle, torch_mod):
             assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
 
 
+def test_repeated_batches_reuse_device_tables(mnw, oracle, torch_mod):
+    """A batch whose job table is byte-identical to the one its ring slot uploaded last skips the upload
+    launch.  The data behind unchanged pointers may change, and a changed table must be uploaded again."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(23)
+    low, high, pixels = 0.0, 250.0, 250000
+    n = 50000
+
+    def column(c):
+        return np.mod(c + 3.0 * rng.standard_normal(n), 250.0).astype(np.float32)
+
+    with mnw.Context(0) as c2:
+        xa, xb = torch.from_numpy(column(40.0)).to(dev), torch.from_numpy(column(200.0)).to(dev)
+        out = torch.zeros(4 * n + 16, dtype=torch.uint8, device=dev)
+        y = torch.empty(n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+
+        def check(xt):
+            x = xt.cpu().numpy()
+            omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
+            jobs = [mnw.EncJob(xt.data_ptr(), out.data_ptr(), n, out.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)]
+            (m,) = c2.encode_blocks(jobs)
+            torch.cuda.synchronize()
+            assert (m.min, m.bits, m.nbytes) == (omin, obits, odata.size)
+            assert out[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+            c2.decode_blocks([mnw.DecJob(out.data_ptr(), y.data_ptr(), n, m.nbytes, m.min, m.bits, mnw.FLOAT_GROUP,
+                                         low, high, pixels, 1, seed=5, block=2)])
+            torch.cuda.synchronize()
+            ref = oracle.float_decode(odata, omin, obits, low, high, pixels, True, n, u=oracle.dither(5, 2, n))
+            assert np.array_equal(y.cpu().numpy(), ref)
+
+        for _ in range(7):                     # the ring has three slots: from the fourth call on, tables repeat
+            check(xa)
+        xa.copy_(torch.from_numpy(column(120.0)).to(dev))      # same pointer, new contents (also a new width/min)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            check(xa)
+        for _ in range(4):                     # another source pointer: the table differs and is uploaded again
+            check(xb)
+            check(xa)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 3 and 4 at reduced row counts (parity-test cases, not bench lines)
 # ------------------------------------------------------------------------------------------------
