@@ -151,6 +151,38 @@ int mnw_encode_blocks_finish(mnw_ctx *ctx, mnw_stream_t stream, mnw_block_meta *
  * The caller synchronises `stream`. */
 int mnw_decode_blocks(mnw_ctx *ctx, mnw_stream_t stream, const mnw_dec_job *jobs, int njobs);
 
+/* ---- minp vector blocks (go/minp/minp.go) ------------------------------------------------------
+ * A minp file stores the particles of one file cell, an array-of-structures grid vec[n_file^3][3], as
+ * 3 * sub_cells^3 FloatGroup blocks: for each component k and sub-cell sc the n_sub^3 values of that
+ * sub-cube (n_sub = n_file / sub_cells), k-major.  Element j = jx + jy*n_sub + jz*n_sub^2 of block
+ * (k, sc) is vec[i][k] with i = (jx + n_sub*sx) + (jy + n_sub*sy)*n_file + (jz + n_sub*sz)*n_file^2 and
+ * sc = sx + sy*sub_cells + sz*sub_cells^2 (getSubCell / setSubCell, minp.go:246-288).
+ * n_file must be a multiple of sub_cells and n_file^3 < 2^31.  All pointers except meta/low/high/pixels are
+ * device pointers; vec and dst 16-byte aligned. */
+
+/* minp.Writer.Vectors up to the file writes (minp.go:85-118): gather every sub-cell and encode block
+ * (k, sc) -- a FloatGroup with limits [low[k], high[k]), pixels[k] and periodic = 1 (writer.go:74) -- to
+ * dst + (k*sub_cells^3 + sc)*slot_bytes.  meta (host, 3*sub_cells^3 entries, k-major like the file) is
+ * filled as by mnw_encode_blocks; synchronous in the same sense. */
+int mnw_vectors_encode(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int64_t n_file, int64_t sub_cells,
+                       const float low[3], const float high[3], const int64_t pixels[3],
+                       uint8_t *dst, int64_t slot_bytes, mnw_block_meta *meta);
+/* minp.Reader.Vectors after the file reads (minp.go:170-198): decode block (k, sc) from
+ * src + (k*sub_cells^3 + sc)*slot_bytes with meta[k*sub_cells^3 + sc].{min,bits,nbytes} (dither key:
+ * seed, block index first_block + k*sub_cells^3 + sc), wrap once into [0, L) if periodic (188-196),
+ * scatter into vec_out (setSubCell).  Enqueue only. */
+int mnw_vectors_decode(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *src, int64_t slot_bytes,
+                       const mnw_block_meta *meta, int64_t n_file, int64_t sub_cells,
+                       const float low[3], const float high[3], const int64_t pixels[3],
+                       int periodic, float L, uint64_t seed, uint64_t first_block, float *vec_out);
+/* bounds() of minp.go:290-300 over vec[n][3] (device): per-component minimum and maximum (host outputs).
+ * The caller applies Nextafter32(max, 2*max) as minp.Writer.Vectors does (minp.go:92-95).  Synchronous. */
+int mnw_vectors_bounds(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int64_t n, float min[3], float max[3]);
+/* The two layout passes alone (device buffers of 3*n_file^3 floats; soa is [k][sc][j]); enqueue only. */
+int mnw_subcell_gather(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int64_t n_file, int64_t sub_cells, float *soa);
+int mnw_subcell_scatter(mnw_ctx *ctx, mnw_stream_t stream, const float *soa, int64_t n_file, int64_t sub_cells,
+                        int periodic, float L, float *vec);
+
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */
 int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
@@ -170,7 +202,10 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_UNPACK_I64  5
 #define MNW_K_ENCODE_F32  6   /* fused float encode: reduce + pack of a whole batch in one persistent launch */
 #define MNW_K_ENCODE_REG_F32 7 /* single-read float encode: the block stays in registers between reduce and pack */
-#define MNW_K_COUNT       8
+#define MNW_K_SUBCELL_GATHER 8  /* minp getSubCell over a whole file cell */
+#define MNW_K_SUBCELL_SCATTER 9 /* minp setSubCell (+ periodic fix-up) */
+#define MNW_K_BOUNDS3     10
+#define MNW_K_COUNT       11
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;
@@ -182,10 +217,9 @@ const char *mnw_kernel_name(int kernel_id);
 
 /* Tunables (0 = default).  group_bytes: blocks are processed in groups whose input is at most this
  * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM.
- * fused: 1 = float batches run as one persistent launch (k_encode_f32), 0 (default) = one reduce and one
- *        pack launch per group.
- * single_read: 1 = float blocks of at most 2^24 elements are encoded by k_encode_reg_f32, which reads each
- *        block once and keeps it in registers; 0 (default) = the reduce + pack launches.
+ * fused: 1 = float batches run as one persistent launch (k_encode_f32); 0 (default) = see single_read.
+ * single_read: 1 (default) = a float batch whose blocks all have at most 2^22 elements is encoded by
+ *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
  * grid_cap: upper bound on workgroups per launch. */
 int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
 

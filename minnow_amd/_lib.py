@@ -10,7 +10,7 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 8
+K_COUNT = 11
 
 
 class MnwError(RuntimeError):
@@ -70,6 +70,13 @@ SIGNATURES = {
     "mnw_unpack_u64_dev": (_int, [_p, _p, _p, _i64, _int, _i64, _p]),
     "mnw_timing_enable": (_int, [_p, _int]),
     "mnw_timing_reset": (_int, [_p]),
+    "mnw_vectors_encode": (_int, [_p, _p, _p, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _i64,
+                                  C.POINTER(BlockMetaC)]),
+    "mnw_vectors_decode": (_int, [_p, _p, _p, _i64, C.POINTER(BlockMetaC), _i64, _i64, C.POINTER(_f32), C.POINTER(_f32),
+                                  C.POINTER(_i64), _int, _f32, _u64, _u64, _p]),
+    "mnw_vectors_bounds": (_int, [_p, _p, _p, _i64, C.POINTER(_f32), C.POINTER(_f32)]),
+    "mnw_subcell_gather": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "mnw_subcell_scatter": (_int, [_p, _p, _p, _i64, _i64, _int, _f32, _p]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),

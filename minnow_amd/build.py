@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminnow_hip.so")
-SOURCES = ["mnw_kernels.hip", "mnw_api.cpp"]
+SOURCES = ["mnw_kernels.hip", "mnw_subcell.hip", "mnw_api.cpp"]
 HEADERS = ["mnw_common.h", os.path.join("..", "..", "include", "minnow_hip.h")]
 
 # -ffp-contract=off: the reference's float32 expressions are never fused (Go on amd64);

@@ -176,6 +176,44 @@ class Context:
         arr = self.dec_batch(jobs)
         self._check(self._L.mnw_decode_blocks(self._h, stream, arr, self._count(arr)))
 
+    # -- minp vector blocks (go/minp/minp.go) ----------------------------------------------------
+    @staticmethod
+    def _f3(v):
+        return (C.c_float * 3)(*[float(x) for x in v])
+
+    @staticmethod
+    def _i3(v):
+        return (C.c_int64 * 3)(*[int(x) for x in v])
+
+    def vectors_bounds(self, vec_ptr, n, stream=None):
+        mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+        self._check(self._L.mnw_vectors_bounds(self._h, stream, vec_ptr, n, mn, mx))
+        return list(mn), list(mx)
+
+    def vectors_encode(self, vec_ptr, n_file, sub_cells, low, high, pixels, dst_ptr, slot_bytes, stream=None, raw=False):
+        nb = 3 * sub_cells ** 3
+        meta = (BlockMetaC * nb)()
+        meta._n = nb
+        self._check(self._L.mnw_vectors_encode(self._h, stream, vec_ptr, n_file, sub_cells, self._f3(low), self._f3(high),
+                                               self._i3(pixels), dst_ptr, slot_bytes, meta))
+        return meta if raw else self.metas_of(meta)
+
+    def vectors_decode(self, src_ptr, slot_bytes, metas, n_file, sub_cells, low, high, pixels, periodic, L, seed, first_block,
+                       vec_out_ptr, stream=None):
+        if isinstance(metas, C.Array):
+            meta = metas
+        else:
+            meta = (BlockMetaC * len(metas))(*[BlockMetaC(m.min, m.bits, m.nbytes, m.status) for m in metas])
+        self._check(self._L.mnw_vectors_decode(self._h, stream, src_ptr, slot_bytes, meta, n_file, sub_cells, self._f3(low),
+                                               self._f3(high), self._i3(pixels), int(bool(periodic)), float(L), seed,
+                                               first_block, vec_out_ptr))
+
+    def subcell_gather(self, vec_ptr, n_file, sub_cells, soa_ptr, stream=None):
+        self._check(self._L.mnw_subcell_gather(self._h, stream, vec_ptr, n_file, sub_cells, soa_ptr))
+
+    def subcell_scatter(self, soa_ptr, n_file, sub_cells, periodic, L, vec_ptr, stream=None):
+        self._check(self._L.mnw_subcell_scatter(self._h, stream, soa_ptr, n_file, sub_cells, int(bool(periodic)), float(L), vec_ptr))
+
     def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
         self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))
 

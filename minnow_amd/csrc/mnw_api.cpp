@@ -27,6 +27,9 @@ int64_t reg_item_elems();
 int encode_reg_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
+void launch_subcell_gather(hipStream_t, int, const float*, float*, int64_t, int64_t);
+void launch_subcell_scatter(hipStream_t, int, const float*, float*, int64_t, int64_t, int, float);
+void launch_bounds3(hipStream_t, int, const float*, int64_t, uint32_t*);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -98,6 +101,12 @@ struct mnw_ctx {
     size_t cap_in = 0, cap_out = 0;
     void* d_in = nullptr;
     void* d_out = nullptr;
+
+    // minp vector blocks: structure-of-arrays staging [3][n_file^3] between the layout pass and the codec
+    size_t cap_soa = 0;
+    float* d_soa = nullptr;
+    uint32_t* d_bkeys = nullptr;  // 8 words: bounds keys
+    uint32_t* h_bkeys = nullptr;  // pinned
 
     // exact path scratch
     size_t cap_q = 0;
@@ -572,6 +581,9 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_UNPACK_I64: return "k_unpack_i64";
         case MNW_K_ENCODE_F32: return "k_encode_f32";
         case MNW_K_ENCODE_REG_F32: return "k_encode_reg_f32";
+        case MNW_K_SUBCELL_GATHER: return "k_subcell_gather";
+        case MNW_K_SUBCELL_SCATTER: return "k_subcell_scatter";
+        case MNW_K_BOUNDS3: return "k_bounds3";
         default: return "";
     }
 }
@@ -607,6 +619,9 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_q) hipFree(c->d_q);
     if (c->d_state) hipFree(c->d_state);
     if (c->d_recs) hipFree(c->d_recs);
+    if (c->d_soa) hipFree(c->d_soa);
+    if (c->d_bkeys) hipFree(c->d_bkeys);
+    if (c->h_bkeys) hipHostFree(c->h_bkeys);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return MNW_OK;
@@ -874,6 +889,128 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     }
     HIPCHK(c, hipGetLastError());
     return release_slot(c, sl, s);
+}
+
+// ---- minp vector blocks (go/minp/minp.go) ------------------------------------------------------
+namespace {
+int vectors_check(mnw_ctx* c, int64_t n_file, int64_t sub_cells, const char* who) {
+    if (!c) return MNW_E_ARG;
+    if (n_file < 1 || sub_cells < 1 || n_file % sub_cells != 0) return fail(c, MNW_E_ARG, who);
+    if (n_file > 1290 || n_file * n_file * n_file >= (1ll << 31)) return fail(c, MNW_E_ARG, "vectors: n_file^3 must be below 2^31");
+    return MNW_OK;
+}
+int ensure_soa(mnw_ctx* c, int64_t n) {
+    void* p = c->d_soa;
+    int rc = ensure_dev(c, &p, &c->cap_soa, (size_t)n * 3 * sizeof(float));
+    c->d_soa = (float*)p;
+    return rc;
+}
+}  // namespace
+
+int mnw_subcell_gather(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_t n_file, int64_t sub_cells, float* soa) {
+    int rc = vectors_check(c, n_file, sub_cells, "gather: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!vec || !soa) return fail(c, MNW_E_ARG, "gather: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    { ScopedTimer t(c, s, MNW_K_SUBCELL_GATHER); mnw::launch_subcell_gather(s, c->cus, vec, soa, n_file, sub_cells); }
+    HIPCHK(c, hipGetLastError());
+    return MNW_OK;
+}
+
+int mnw_subcell_scatter(mnw_ctx* c, mnw_stream_t stream, const float* soa, int64_t n_file, int64_t sub_cells, int periodic, float L,
+                        float* vec) {
+    int rc = vectors_check(c, n_file, sub_cells, "scatter: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!vec || !soa) return fail(c, MNW_E_ARG, "scatter: null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    { ScopedTimer t(c, s, MNW_K_SUBCELL_SCATTER); mnw::launch_subcell_scatter(s, c->cus, soa, vec, n_file, sub_cells, periodic != 0, L); }
+    HIPCHK(c, hipGetLastError());
+    return MNW_OK;
+}
+
+int mnw_vectors_bounds(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_t n, float mn[3], float mx[3]) {
+    if (!c || !vec || n < 1 || !mn || !mx) return fail(c, MNW_E_ARG, "bounds: bad arguments");   // bounds() reads vec[0]
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!c->d_bkeys) {
+        HIPCHK(c, hipMalloc((void**)&c->d_bkeys, 8 * sizeof(uint32_t)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_bkeys, 8 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_bkeys, 0, 8 * sizeof(uint32_t), s));
+    { ScopedTimer t(c, s, MNW_K_BOUNDS3); mnw::launch_bounds3(s, c->cus, vec, n, c->d_bkeys); }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_bkeys, c->d_bkeys, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    auto unkey = [](uint32_t k) { uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu); float f; memcpy(&f, &u, 4); return f; };
+    for (int k = 0; k < 3; ++k) {
+        if (c->h_bkeys[2 * k] == 0 || c->h_bkeys[2 * k + 1] == 0) return fail(c, MNW_E_DOMAIN, "bounds: a component holds no ordered value (all NaN)");
+        mx[k] = unkey(c->h_bkeys[2 * k]);
+        mn[k] = unkey(~c->h_bkeys[2 * k + 1]);
+    }
+    return MNW_OK;
+}
+
+int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_t n_file, int64_t sub_cells,
+                       const float low[3], const float high[3], const int64_t pixels[3],
+                       uint8_t* dst, int64_t slot_bytes, mnw_block_meta* meta) {
+    int rc = vectors_check(c, n_file, sub_cells, "vectors: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!vec || !dst || !meta || !low || !high || !pixels || slot_bytes < 0 || (slot_bytes & 15) || ((uintptr_t)dst & 15))
+        return fail(c, MNW_E_ARG, "vectors: null or misaligned pointer, or slot_bytes not a multiple of 16");
+    const int64_t n = n_file * n_file * n_file, s3 = sub_cells * sub_cells * sub_cells, nsub3 = n / s3;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = ensure_soa(c, n);
+    if (rc) return rc;
+    { ScopedTimer t(c, s, MNW_K_SUBCELL_GATHER); mnw::launch_subcell_gather(s, c->cus, vec, c->d_soa, n_file, sub_cells); }
+    HIPCHK(c, hipGetLastError());
+    std::vector<mnw_enc_job> jobs((size_t)(3 * s3));
+    for (int k = 0; k < 3; ++k) {
+        for (int64_t sc = 0; sc < s3; ++sc) {
+            mnw_enc_job& j = jobs[(size_t)(k * s3 + sc)];
+            memset(&j, 0, sizeof j);
+            j.src = c->d_soa + (size_t)k * n + (size_t)sc * nsub3;
+            j.dst = dst + (size_t)(k * s3 + sc) * slot_bytes;
+            j.n = nsub3; j.cap = slot_bytes;
+            j.kind = MNW_FLOAT_GROUP; j.low = low[k]; j.high = high[k]; j.pixels = pixels[k];
+            j.periodic = 1;                                   // Writer.FloatGroup, writer.go:74
+        }
+    }
+    return mnw_encode_blocks(c, stream, jobs.data(), (int)jobs.size(), meta);
+}
+
+int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int64_t slot_bytes, const mnw_block_meta* meta,
+                       int64_t n_file, int64_t sub_cells, const float low[3], const float high[3], const int64_t pixels[3],
+                       int periodic, float L, uint64_t seed, uint64_t first_block, float* vec_out) {
+    int rc = vectors_check(c, n_file, sub_cells, "vectors: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!src || !vec_out || !meta || !low || !high || !pixels || slot_bytes < 0)
+        return fail(c, MNW_E_ARG, "vectors: null pointer");
+    const int64_t n = n_file * n_file * n_file, s3 = sub_cells * sub_cells * sub_cells, nsub3 = n / s3;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = ensure_soa(c, n);
+    if (rc) return rc;
+    std::vector<mnw_dec_job> jobs((size_t)(3 * s3));
+    for (int k = 0; k < 3; ++k) {
+        for (int64_t sc = 0; sc < s3; ++sc) {
+            const size_t b = (size_t)(k * s3 + sc);
+            mnw_dec_job& j = jobs[b];
+            memset(&j, 0, sizeof j);
+            j.src = src + b * (size_t)slot_bytes;
+            j.dst = c->d_soa + (size_t)k * n + (size_t)sc * nsub3;
+            j.n = nsub3; j.src_len = meta[b].nbytes; j.min = meta[b].min; j.bits = meta[b].bits;
+            j.kind = MNW_FLOAT_GROUP; j.low = low[k]; j.high = high[k]; j.pixels = pixels[k]; j.periodic = 1;
+            j.seed = seed; j.block = first_block + b;
+        }
+    }
+    rc = mnw_decode_blocks(c, stream, jobs.data(), (int)jobs.size());
+    if (rc) return rc;
+    { ScopedTimer t(c, s, MNW_K_SUBCELL_SCATTER); mnw::launch_subcell_scatter(s, c->cus, c->d_soa, vec_out, n_file, sub_cells, periodic != 0, L); }
+    HIPCHK(c, hipGetLastError());
+    return MNW_OK;
 }
 
 // ---- raw bit.Array on device buffers ----------------------------------------------------------

@@ -436,3 +436,78 @@ int64_t mnwo_tail_array_decode(const uint8_t *in, int64_t blocks, int64_t *out) 
     free(tmp);
     return rc;
 }
+
+/* ---- minp sub-cells ------------------------------------------------------------------------ */
+/* go/minp/minp.go:246-266 */
+void mnwo_get_sub_cell(const float *x, float *buf0, float *buf1, float *buf2, int64_t sc,
+                       int64_t sub_cells, int64_t n_sub) {
+    float *buf[3];
+    int64_t n_file = n_sub * sub_cells;
+    int64_t sx = sc % sub_cells, sy = (sc / sub_cells) % sub_cells, sz = sc / (sub_cells * sub_cells);
+    int64_t ix0 = n_sub * sx, iy0 = n_sub * sy, iz0 = n_sub * sz;
+    int64_t j = 0, jx, jy, jz;
+    int k;
+    buf[0] = buf0; buf[1] = buf1; buf[2] = buf2;
+    for (jz = 0; jz < n_sub; jz++)
+        for (jy = 0; jy < n_sub; jy++)
+            for (jx = 0; jx < n_sub; jx++) {
+                int64_t ix = jx + ix0, iy = jy + iy0, iz = jz + iz0;
+                int64_t i = ix + iy * n_file + iz * n_file * n_file;
+                for (k = 0; k < 3; k++) buf[k][j] = x[3 * i + k];
+                j++;
+            }
+}
+
+/* go/minp/minp.go:272-288 */
+void mnwo_set_sub_cell(float *x, const float *buf0, const float *buf1, const float *buf2, int64_t sc,
+                       int64_t sub_cells, int64_t n_sub) {
+    const float *buf[3];
+    int64_t n_file = n_sub * sub_cells;
+    int64_t sx = sc % sub_cells, sy = (sc / sub_cells) % sub_cells, sz = sc / (sub_cells * sub_cells);
+    int64_t ix0 = n_sub * sx, iy0 = n_sub * sy, iz0 = n_sub * sz;
+    int64_t j = 0, jx, jy, jz;
+    int k;
+    buf[0] = buf0; buf[1] = buf1; buf[2] = buf2;
+    for (jz = 0; jz < n_sub; jz++)
+        for (jy = 0; jy < n_sub; jy++)
+            for (jx = 0; jx < n_sub; jx++) {
+                int64_t ix = jx + ix0, iy = jy + iy0, iz = jz + iz0;
+                int64_t i = ix + iy * n_file + iz * n_file * n_file;
+                for (k = 0; k < 3; k++) x[3 * i + k] = buf[k][j];
+                j++;
+            }
+}
+
+/* go/minp/minp.go:290-300 */
+void mnwo_bounds3(const float *vec, int64_t n, float *min3, float *max3) {
+    int64_t i;
+    int k;
+    for (k = 0; k < 3; k++) { min3[k] = vec[k]; max3[k] = vec[k]; }
+    for (i = 0; i < n; i++)
+        for (k = 0; k < 3; k++) {
+            if (vec[3 * i + k] < min3[k]) min3[k] = vec[3 * i + k];
+            if (vec[3 * i + k] > max3[k]) max3[k] = vec[3 * i + k];
+        }
+}
+
+/* go/minp/minp.go:188-196 */
+void mnwo_periodic_fix(float *x, int64_t n, float L) {
+    int64_t i;
+    for (i = 0; i < n; i++) {
+        if (x[i] < 0) x[i] = x[i] + L;
+        else if (x[i] >= L) x[i] = x[i] - L;
+    }
+}
+
+/* Go src/math/nextafter.go Nextafter32: NaN if either is NaN; x if x == y; smallest subnormal with
+ * y's sign if x == 0; else step the bit pattern towards y. */
+float mnwo_nextafter32(float x, float y) {
+    uint32_t u;
+    if (x != x || y != y) return x != x ? x : y;
+    if (x == y) return x;
+    if (x == 0) { u = 1; memcpy(&x, &u, 4); return y > 0 ? x : -x; }
+    memcpy(&u, &x, 4);
+    if ((y > x) == (x > 0)) u++; else u--;
+    memcpy(&x, &u, 4);
+    return x;
+}

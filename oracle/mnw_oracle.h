@@ -102,6 +102,19 @@ int64_t mnwo_tail_array_encode(const int64_t *x, int64_t n, uint8_t *out);
 /* go/group.go:190-198 read(): returns bytes consumed */
 int64_t mnwo_tail_array_decode(const uint8_t *in, int64_t blocks, int64_t *out);
 
+/* ---- minp sub-cells (go/minp/minp.go) ---------------------------------------------------
+ * getSubCell / setSubCell (minp.go:246-288): x is [n_file^3][3] floats, buf k holds n_sub^3. */
+void mnwo_get_sub_cell(const float *x, float *buf0, float *buf1, float *buf2, int64_t sc,
+                       int64_t sub_cells, int64_t n_sub);
+void mnwo_set_sub_cell(float *x, const float *buf0, const float *buf1, const float *buf2, int64_t sc,
+                       int64_t sub_cells, int64_t n_sub);
+/* bounds (minp.go:290-300) */
+void mnwo_bounds3(const float *vec, int64_t n, float *min3, float *max3);
+/* the reader's periodic fix-up (minp.go:188-196), in place */
+void mnwo_periodic_fix(float *x, int64_t n, float L);
+/* math.Nextafter32(x, y) (Go src/math/nextafter.go), used by minp.go:94 */
+float mnwo_nextafter32(float x, float y);
+
 #ifdef __cplusplus
 }
 #endif

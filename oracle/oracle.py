@@ -58,6 +58,11 @@ def lib():
             "mnwo_dither_fill": (None, [u64, u64, i64, p]),
             "mnwo_tail_array_encode": (i64, [p, i64, p]),
             "mnwo_tail_array_decode": (i64, [p, i64, p]),
+            "mnwo_get_sub_cell": (None, [p, p, p, p, i64, i64, i64]),
+            "mnwo_set_sub_cell": (None, [p, p, p, p, i64, i64, i64]),
+            "mnwo_bounds3": (None, [p, i64, p, p]),
+            "mnwo_periodic_fix": (None, [p, i64, f32]),
+            "mnwo_nextafter32": (f32, [f32, f32]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -256,3 +261,74 @@ def tail_array_decode(data, blocks):
     if n < 0:
         raise ValueError("oracle tail decode failed")
     return out, int(n)
+
+
+# ---- minp sub-cells (go/minp/minp.go) --------------------------------------------------------------
+def get_sub_cell(vec, sc, sub_cells, n_sub):
+    """getSubCell (minp.go:246-266): vec is [n_file^3, 3] float32 -> three arrays of n_sub^3"""
+    vec = _c(vec, np.float32)
+    bufs = [np.empty(n_sub ** 3, dtype=np.float32) for _ in range(3)]
+    lib().mnwo_get_sub_cell(_ptr(vec), _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]), sc, sub_cells, n_sub)
+    return bufs
+
+
+def set_sub_cell(vec, bufs, sc, sub_cells, n_sub):
+    """setSubCell (minp.go:272-288), in place on the C-contiguous float32 array vec"""
+    assert vec.dtype == np.float32 and vec.flags.c_contiguous
+    b = [_c(x, np.float32) for x in bufs]
+    lib().mnwo_set_sub_cell(_ptr(vec), _ptr(b[0]), _ptr(b[1]), _ptr(b[2]), sc, sub_cells, n_sub)
+
+
+def bounds3(vec):
+    vec = _c(vec, np.float32)
+    mn, mx = np.empty(3, dtype=np.float32), np.empty(3, dtype=np.float32)
+    lib().mnwo_bounds3(_ptr(vec), vec.size // 3, _ptr(mn), _ptr(mx))
+    return mn, mx
+
+
+def nextafter32(x, y):
+    return np.float32(lib().mnwo_nextafter32(float(np.float32(x)), float(np.float32(y))))
+
+
+def minp_limits(vec, periodic, L):
+    """the (min, max) per component that minp.Writer.Vectors hands to FloatGroup (minp.go:86-96)"""
+    if periodic:
+        return np.zeros(3, dtype=np.float32), np.full(3, np.float32(L), dtype=np.float32)
+    mn, mx = bounds3(vec)
+    mx = np.array([nextafter32(m, np.float32(2) * m) for m in mx], dtype=np.float32)
+    return mn, mx
+
+
+def minp_vectors_encode(vec, n_file, sub_cells, dx, periodic, L):
+    """minp.Writer.Vectors (minp.go:85-118) up to the file writes: [(min, bits, bytes)] in file order
+    (k-major), plus the limits and pixels of the three groups."""
+    n_sub = n_file // sub_cells
+    mn, mx = minp_limits(vec, periodic, L)
+    blocks, pix = [], []
+    for k in range(3):
+        pixels = float_group_pixels(mn[k], mx[k], dx)
+        pix.append(pixels)
+        for sc in range(sub_cells ** 3):
+            buf = get_sub_cell(vec, sc, sub_cells, n_sub)[k]
+            blocks.append(float_encode(buf, mn[k], mx[k], pixels, True, literal=False))
+    return blocks, mn, mx, pix
+
+
+def minp_vectors_decode(blocks, n_file, sub_cells, mn, mx, pix, periodic, L, seed, first_block=0):
+    """minp.Reader.Vectors (minp.go:170-198) after the file reads, with the build's dither"""
+    n_sub = n_file // sub_cells
+    s3, n3 = sub_cells ** 3, n_sub ** 3
+    out = np.zeros((n_file ** 3, 3), dtype=np.float32)
+    for sc in range(s3):
+        bufs = []
+        for k in range(3):
+            b = k * s3 + sc
+            m, bits, data = blocks[b]
+            x = float_decode(data, m, bits, mn[k], mx[k], pix[k], True, n3, u=dither(seed, first_block + b, n3),
+                             literal=False)
+            if periodic:
+                x = np.ascontiguousarray(x, dtype=np.float32)
+                lib().mnwo_periodic_fix(_ptr(x), n3, float(np.float32(L)))
+            bufs.append(x)
+        set_sub_cell(out, bufs, sc, sub_cells, n_sub)
+    return out

@@ -199,3 +199,45 @@ def test_periodic_reduction_identity(oracle):
         n = int(rng.integers(1, 14))
         q = rng.integers(0, pixels, size=n).astype(np.int64)
         assert by_reduction(q, pixels) == oracle.periodic_min(q, pixels), (pixels, q)
+
+
+# ---- minp sub-cells (go/minp/minp.go:246-300) --------------------------------------------------------
+def test_minp_get_set_sub_cell_reference_test(oracle):
+    """TestGetSubCell of go/minp/minp_test.go:168-207, restated on the oracle"""
+    n_sub, sub_cells = 2, 3
+    nf = n_sub * sub_cells
+    inb = [np.arange(n_sub ** 3, dtype=np.float32) * m for m in (1, 10, 100)]
+    vec = np.zeros((nf ** 3, 3), dtype=np.float32)
+    for sc in range(sub_cells ** 3):
+        inb = [b + 1 for b in inb]
+        oracle.set_sub_cell(vec, inb, sc, sub_cells, n_sub)
+        out = oracle.get_sub_cell(vec, sc, sub_cells, n_sub)
+        assert all(np.array_equal(a, b) for a, b in zip(inb, out))
+
+
+def test_minp_sub_cell_against_numpy_reshape(oracle):
+    """the literal loops equal the obvious reshape/transposition"""
+    rng = np.random.default_rng(3)
+    for n_sub, s in ((3, 2), (2, 3), (5, 1)):
+        nf = n_sub * s
+        vec = rng.standard_normal((nf ** 3, 3)).astype(np.float32)
+        cube = vec.reshape(nf, nf, nf, 3)            # [iz, iy, ix, k]
+        for sc in range(s ** 3):
+            sx, sy, sz = sc % s, (sc // s) % s, sc // (s * s)
+            sub = cube[sz * n_sub:(sz + 1) * n_sub, sy * n_sub:(sy + 1) * n_sub, sx * n_sub:(sx + 1) * n_sub]
+            ref = oracle.get_sub_cell(vec, sc, s, n_sub)
+            for k in range(3):
+                assert np.array_equal(ref[k], sub[..., k].reshape(-1))
+
+
+def test_minp_nextafter32_and_limits(oracle):
+    assert oracle.nextafter32(1.0, 2.0) == np.nextafter(np.float32(1), np.float32(2))
+    assert oracle.nextafter32(-3.0, -6.0) == np.nextafter(np.float32(-3), np.float32(-6))     # steps away from zero
+    assert oracle.nextafter32(0.0, 0.0) == 0.0
+    assert oracle.nextafter32(0.0, -1.0) == -np.float32(1e-45)
+    vec = np.array([[1, -5, -9], [4, -2, -7]], dtype=np.float32)
+    mn, mx = oracle.minp_limits(vec, False, 0.0)
+    assert list(mn) == [1, -5, -9]
+    assert mx[0] == np.nextafter(np.float32(4), np.float32(8)) and mx[1] == np.nextafter(np.float32(-2), np.float32(-4))
+    mn, mx = oracle.minp_limits(vec, True, 100.0)
+    assert list(mn) == [0, 0, 0] and list(mx) == [100, 100, 100]
