@@ -205,7 +205,10 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_SUBCELL_GATHER 8  /* minp getSubCell over a whole file cell */
 #define MNW_K_SUBCELL_SCATTER 9 /* minp setSubCell (+ periodic fix-up) */
 #define MNW_K_BOUNDS3     10
-#define MNW_K_COUNT       11
+#define MNW_K_REDUCE_VEC3 11  /* minp vectors without staging: statistics of the three blocks of every sub-cell */
+#define MNW_K_PACK_VEC3   12  /* ... and their pack, straight from the array-of-structures grid */
+#define MNW_K_UNPACK_VEC3 13  /* minp vectors without staging: the three streams of a sub-cell into the grid */
+#define MNW_K_COUNT       14
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;
@@ -220,6 +223,9 @@ const char *mnw_kernel_name(int kernel_id);
  * fused: 1 = float batches run as one persistent launch (k_encode_f32); 0 (default) = see single_read.
  * single_read: 1 (default) = a float batch whose blocks all have at most 2^22 elements is encoded by
  *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
+ * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels
+ *        when the geometry allows (n_sub and n_file multiples of four); 0 = always gather into the staging
+ *        buffer first and run the block encoder on that.
  * grid_cap: upper bound on workgroups per launch. */
 int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
 

@@ -10,7 +10,7 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 11
+K_COUNT = 14
 
 
 class MnwError(RuntimeError):

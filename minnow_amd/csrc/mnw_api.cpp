@@ -30,6 +30,10 @@ void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
 void launch_subcell_gather(hipStream_t, int, const float*, float*, int64_t, int64_t);
 void launch_subcell_scatter(hipStream_t, int, const float*, float*, int64_t, int64_t, int, float);
 void launch_bounds3(hipStream_t, int, const float*, int64_t, uint32_t*);
+void launch_reduce_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, uint64_t*);
+void launch_pack_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, const uint64_t*, Meta*);
+int64_t vec3_tiles(int64_t, int64_t);
+void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -124,6 +128,7 @@ struct mnw_ctx {
     int64_t group_bytes = 1ll << 40;   // two-kernel path: all blocks of a batch in one reduce + one pack launch
     int grid_cap = 0;
     int fused = 0;               // float encode as one persistent launch per batch (k_encode_f32): opt-in, see DESIGN.md
+    int vec3_fused = 1;          // minp vectors: reduce + pack straight from the AoS grid when the geometry allows
     int single_read = 1;         // float encode through k_encode_reg_f32 (block read once) whenever the batch is eligible
     int reg_blocks_per_cu = 0;   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
@@ -584,6 +589,9 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_SUBCELL_GATHER: return "k_subcell_gather";
         case MNW_K_SUBCELL_SCATTER: return "k_subcell_scatter";
         case MNW_K_BOUNDS3: return "k_bounds3";
+        case MNW_K_REDUCE_VEC3: return "k_reduce_vec3";
+        case MNW_K_PACK_VEC3: return "k_pack_vec3";
+        case MNW_K_UNPACK_VEC3: return "k_unpack_vec3";
         default: return "";
     }
 }
@@ -632,6 +640,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (1ll << 40); return MNW_OK; }
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
     return fail(c, MNW_E_ARG, "unknown option");
 }
@@ -962,6 +971,53 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
     const int64_t n = n_file * n_file * n_file, s3 = sub_cells * sub_cells * sub_cells, nsub3 = n / s3;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // ---- without staging: the reduce and the pack read the grid themselves (k_reduce_vec3 / k_pack_vec3) ----
+    bool fused = c->vec3_fused && !c->pending && (n_file / sub_cells) % 4 == 0 && n_file % 4 == 0 && ((uintptr_t)vec & 15) == 0 &&
+                 3 * s3 < (1 << 20);
+    for (int k = 0; k < 3 && fused; ++k) {
+        mnw_enc_job probe;
+        memset(&probe, 0, sizeof probe);
+        probe.low = low[k]; probe.high = high[k]; probe.pixels = pixels[k]; probe.kind = MNW_FLOAT_GROUP;
+        fused = pixels[k] > 0 && pixels[k] <= 0x7fffffffll && float_fast_ok(probe);
+    }
+    if (fused) {
+        JobSlot* sl;
+        rc = acquire_slot(c, (int)(3 * s3), &sl);
+        if (rc) return rc;
+        for (int k = 0; k < 3; ++k) {
+            for (int64_t sc = 0; sc < s3; ++sc) {
+                mnw_enc_job j;
+                memset(&j, 0, sizeof j);
+                j.src = vec; j.dst = dst + (size_t)(k * s3 + sc) * slot_bytes; j.n = nsub3; j.cap = slot_bytes;
+                j.kind = MNW_FLOAT_GROUP; j.low = low[k]; j.high = high[k]; j.pixels = pixels[k]; j.periodic = 1;
+                fill_enc(sl->h_jobs[k * s3 + sc], j);
+            }
+        }
+        rc = prepare_slot(c, sl, s, (int)(3 * s3), true);
+        if (rc) return rc;
+        const int64_t vt = mnw::vec3_tiles(n_file, sub_cells);
+        int gr = c->cus * 8, gp = c->cus * 4;
+        if (gr > vt) gr = (int)vt;
+        if (gp > vt) gp = (int)vt;
+        { ScopedTimer t(c, s, MNW_K_REDUCE_VEC3); mnw::launch_reduce_vec3(s, gr, vec, n_file, sub_cells, sl->d_jobs, sl->d_stats); }
+        { ScopedTimer t(c, s, MNW_K_PACK_VEC3); mnw::launch_pack_vec3(s, gp, vec, n_file, sub_cells, sl->d_jobs, sl->d_stats, sl->d_meta); }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));
+        bool exact = false;
+        int first = MNW_OK;
+        for (int64_t b = 0; b < 3 * s3; ++b) {
+            const Meta& m = sl->h_meta[b];
+            if (m.status == mnw::kNeedsExact) exact = true;
+            else if (m.status != 0 && first == MNW_OK) first = (int)m.status;
+        }
+        if (!exact) {
+            memcpy(meta, sl->h_meta, sizeof(Meta) * (size_t)(3 * s3));
+            if (first != MNW_OK) fail(c, first, mnw_strerror(first));
+            return first;
+        }
+        // some block is order dependent (NaN, values outside [low, high), ...): redo the call through the staging
+        // path, whose block encoder has the exact path behind it
+    }
     rc = ensure_soa(c, n);
     if (rc) return rc;
     { ScopedTimer t(c, s, MNW_K_SUBCELL_GATHER); mnw::launch_subcell_gather(s, c->cus, vec, c->d_soa, n_file, sub_cells); }
@@ -991,6 +1047,46 @@ int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int6
     const int64_t n = n_file * n_file * n_file, s3 = sub_cells * sub_cells * sub_cells, nsub3 = n / s3;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // ---- without staging: k_unpack_vec3 writes the grid itself --------------------------------------------
+    bool fused = c->vec3_fused && !c->pending && (n_file / sub_cells) % 4 == 0 && n_file % 4 == 0 && ((uintptr_t)vec_out & 15) == 0 &&
+                 3 * s3 < (1 << 20);
+    for (int64_t b = 0; b < 3 * s3 && fused; ++b) {
+        const int k = (int)(b / s3);
+        const mnw_block_meta& m = meta[b];
+        if (m.bits < 0 || m.bits > 64) return fail(c, MNW_E_ARG, "decode: bits outside 0..64");
+        if (m.bits > 0 && m.nbytes < mnw::array_bytes(m.bits, nsub3)) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
+        fused = m.bits <= 32 && pixels[k] > 0 && pixels[k] <= 0x7fffffffll && m.min >= -0x80000000ll &&
+                m.min + (int64_t)((1ull << m.bits) - 1) <= 0x7fffffffll;
+    }
+    if (fused) {
+        JobSlot* sl;
+        rc = acquire_slot(c, (int)(3 * s3), &sl, true);
+        if (rc) return rc;
+        for (int k = 0; k < 3; ++k) {
+            const float dxq = quant_dx(low[k], high[k], pixels[k]);                 // group.go:305-306
+            for (int64_t sc = 0; sc < s3; ++sc) {
+                const size_t b = (size_t)(k * s3 + sc);
+                DevJob& d = sl->h_jobs[b];
+                memset(&d, 0, sizeof d);
+                d.src = src + b * (size_t)slot_bytes; d.dst = vec_out; d.n = nsub3; d.cap = meta[b].nbytes; d.pixels = pixels[k];
+                d.min = meta[b].min; d.bits = (int32_t)meta[b].bits; d.seed = seed; d.block = first_block + b;
+                d.low = low[k]; d.high = high[k]; d.kind = MNW_FLOAT_GROUP; d.periodic = 1; d.mode = mnw::kModeExplicit;
+                d.dxq = dxq;
+            }
+        }
+        const size_t table_bytes = sizeof(DevJob) * (size_t)(3 * s3);
+        if (!tables_unchanged(sl, 1, table_bytes)) {
+            rc = prepare_slot(c, sl, s, (int)(3 * s3), false);
+            if (rc) return rc;
+            remember_tables(sl, 1, table_bytes);
+        }
+        const int64_t vt = mnw::vec3_tiles(n_file, sub_cells);
+        int g = c->cus * 8;
+        if (g > vt) g = (int)vt;
+        { ScopedTimer t(c, s, MNW_K_UNPACK_VEC3); mnw::launch_unpack_vec3(s, g, vec_out, n_file, sub_cells, sl->d_jobs, periodic != 0, L); }
+        HIPCHK(c, hipGetLastError());
+        return release_slot(c, sl, s);
+    }
     rc = ensure_soa(c, n);
     if (rc) return rc;
     std::vector<mnw_dec_job> jobs((size_t)(3 * s3));

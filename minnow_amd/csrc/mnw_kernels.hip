@@ -1746,6 +1746,8 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict
     for (int64_t i = i0; i < zero1_words; i += step) zero1[i] = 0;
 }
 
+#include "mnw_subcell.hip"
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)
 // ------------------------------------------------------------------------------------------------

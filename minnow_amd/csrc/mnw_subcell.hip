@@ -12,10 +12,7 @@
 // sc = sx + sy*S + sz*S^2 (minp.go:247-262).  A thread owns one output index g = sc*nSub^3 + j, or four
 // consecutive ones when nSub and nFile are multiples of four (the four particles are then 48 contiguous,
 // 16-byte aligned bytes of vec, and the three outputs are 16-byte vectors).  All HBM bound; no LDS.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-namespace mnw {
+// (This file is included by mnw_kernels.hip, inside namespace mnw, after the float-group helpers it uses.)
 
 #define MNW_GLOBAL_SC __attribute__((address_space(1)))
 typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
@@ -150,6 +147,315 @@ __global__ __launch_bounds__(256) void k_bounds3(const float* __restrict__ vec, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// minp.Writer.Vectors without the staging pass: the float-group reduce and pack read the AoS grid directly.
+//
+// A vtile = 2,048 consecutive elements j of one sub-cell, all three components: 24 KB of the grid, read as
+// 512 groups of four particles (48 contiguous bytes, three 16-byte loads; two groups per lane).  Jobs are
+// the 3*S^3 blocks in file order (job = k*S^3 + sc).
+//   k_reduce_vec3  folds every vtile into the statistics of its three blocks (stat lines, as k_reduce_f32)
+//   k_pack_vec3    derives the three descriptors of a sub-cell from the stat lines itself (the kernel
+//                  boundary is the barrier; the workgroup that packs a block's first vtile writes its
+//                  metadata), quantizes at load time, parks the three components as three LDS planes in
+//                  the pack core's staging layout; wave w packs component w and writes its words out
+//                  itself (wave-local: no barrier between pack and store).
+// HBM traffic: 12 B/particle twice + the streams, against 12 B read + 12 B written + 12 B read + streams
+// of the staging path (k_subcell_gather + the block encoder).
+// Only for n_sub, n_file multiples of four and ring sizes the 32-bit pack path takes; anything else, and any
+// block the descriptor sends to the exact path, goes through the staging path.
+// ------------------------------------------------------------------------------------------------
+constexpr int kVTile = 2048;
+constexpr int kVPlane = kVTile / kGroup * kStride32;          // dwords of one component plane (2,304)
+
+struct Vec3Args {
+    const float* vec;
+    SubcellGeom gm;
+    uint32_t s3;              // sub_cells^3
+    uint32_t tiles_per_sc;    // vtiles per sub-cell
+};
+
+// the lane's two groups of four particles of vtile (sc, t): de-interleaved values, or `valid` false past the end
+struct Vec3Group {
+    sc_f32x4 x, y, z;
+    bool valid;
+};
+__device__ __forceinline__ Vec3Group vec3_load(const Vec3Args& a, uint32_t sc, uint32_t j) {
+    Vec3Group g;
+    g.valid = j < a.gm.n_sub3;
+    if (g.valid) {
+        const uint32_t i = particle_of(a.gm, sc * a.gm.n_sub3 + j);
+        const MNW_GLOBAL_SC sc_f32x4* p = (const MNW_GLOBAL_SC sc_f32x4*)(a.vec + 3 * (int64_t)i);
+        const sc_f32x4 u = p[0], v = p[1], w = p[2];
+        g.x = sc_f32x4{u.x, u.w, v.z, w.y}; g.y = sc_f32x4{u.y, v.x, v.w, w.z}; g.z = sc_f32x4{u.z, v.y, w.x, w.w};
+    } else {
+        g.x = g.y = g.z = sc_f32x4{0, 0, 0, 0};
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(256, 4) void k_reduce_vec3(Vec3Args a, const DevJob* __restrict__ jobs, uint64_t* __restrict__ stats) {
+    __shared__ float red[12][4];
+    __shared__ int redbad[3][4];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)a.s3 * a.tiles_per_sc;
+    int64_t v0 = total * blockIdx.x / gridDim.x;
+    const int64_t v1 = total * (blockIdx.x + 1) / gridDim.x;
+    while (v0 < v1) {
+        const uint32_t sc = (uint32_t)(v0 / a.tiles_per_sc);
+        int64_t vend = (int64_t)(sc + 1) * a.tiles_per_sc;
+        if (vend > v1) vend = v1;
+        float xh[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xh[k] = jobs[k * a.s3 + sc].xh;
+        FStat st[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st[k] = FStat{INFINITY, -INFINITY, -INFINITY, INFINITY, false};
+        for (int64_t v = v0; v < vend; ++v) {
+            const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
+            Vec3Group g[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) g[r] = vec3_load(a, sc, t * kVTile + 4 * (tid + 256 * r));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (g[r].valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { fstat_add(st[0], g[r].x[c], xh[0]); fstat_add(st[1], g[r].y[c], xh[1]); fstat_add(st[2], g[r].z[c], xh[2]); }
+                }
+            }
+        }
+        // fold the run into the three blocks' stat lines
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float mn = wave_min_dpp(st[k].mn), mx = wave_max_dpp(st[k].mx), mxlo = wave_max_dpp(st[k].mxlo), mnhi = wave_min_dpp(st[k].mnhi);
+            const int bad = __any(st[k].bad);
+            if (lane_id() == 0) {
+                red[4 * k][wave_id()] = mn; red[4 * k + 1][wave_id()] = mx; red[4 * k + 2][wave_id()] = mxlo; red[4 * k + 3][wave_id()] = mnhi;
+                redbad[k][wave_id()] = bad;
+            }
+        }
+        __syncthreads();
+        if (tid < 15) {
+            const int k = tid / 5, w5 = tid % 5;
+            float aa = red[4 * k][0], bb = red[4 * k + 1][0], cc = red[4 * k + 2][0], dd = red[4 * k + 3][0];
+            int bd = redbad[k][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                aa = fminf(aa, red[4 * k][w]); bb = fmaxf(bb, red[4 * k + 1][w]);
+                cc = fmaxf(cc, red[4 * k + 2][w]); dd = fminf(dd, red[4 * k + 3][w]);
+                bd |= redbad[k][w];
+            }
+            uint64_t val;
+            if (w5 == 0) val = bd ? 0 : fkey(bb);
+            else if (w5 == 1) val = bd ? 0 : (uint32_t)~fkey(aa);
+            else if (w5 == 2) val = (bd || cc == -INFINITY) ? 0 : fkey(cc);
+            else if (w5 == 3) val = (bd || dd == INFINITY) ? 0 : (uint32_t)~fkey(dd);
+            else val = bd ? 1 : 0;
+            const int64_t j = (int64_t)k * a.s3 + sc;
+            uint64_t* rec = stats + (j * kStatSlots + (blockIdx.x % kStatSlots)) * kStatWords;
+            if (val != 0) atomicMax((unsigned long long*)(rec + w5), (unsigned long long)val);
+        }
+        v0 = vend;
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* __restrict__ jobs, const uint64_t* __restrict__ stats,
+                                                      Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * kVPlane];
+    __shared__ uint64_t gran_s[3];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)a.s3 * a.tiles_per_sc;
+    int64_t v0 = total * blockIdx.x / gridDim.x;
+    const int64_t v1 = total * (blockIdx.x + 1) / gridDim.x;
+    while (v0 < v1) {
+        const uint32_t sc = (uint32_t)(v0 / a.tiles_per_sc);
+        int64_t vend = (int64_t)(sc + 1) * a.tiles_per_sc;
+        if (vend > v1) vend = v1;
+        // ---- the three descriptors of this sub-cell (wave k derives block k's) ------------------------
+        __syncthreads();
+        if (wave_id() < 3) {
+            const int64_t j = (int64_t)wave_id() * a.s3 + sc;
+            const DevJob jb = jobs[j];
+            uint64_t st[5];
+            load_stats<false>(stats, (int)j, st);
+            const Desc d = make_desc_f32(jb, st);
+            if (lane_id() == 0) {
+                gran_s[wave_id()] = gran_encode(d);
+                if (v0 == (int64_t)sc * a.tiles_per_sc) {          // this workgroup packs the sub-cell's first vtile
+                    Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+                    meta[j] = m;
+                }
+            }
+        }
+        __syncthreads();
+        float low[3];
+        double rdx[3];
+        float dxq[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * a.s3 + sc]; low[k] = jb.low; rdx[k] = jb.rdx; dxq[k] = jb.dxq; }
+        // the packing wave's own block
+        const int kw = wave_id() < 3 ? wave_id() : 0;
+        const DevJob jw = jobs[(int64_t)kw * a.s3 + sc];
+        const Desc dw = gran_decode(gran_s[kw], jw.n);
+        const int okw = __builtin_amdgcn_readfirstlane(wave_id() < 3 && dw.status == 0 && dw.bits != 0);
+        const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane(dw.bits);
+        const uint32_t iminw = (uint32_t)(int32_t)dw.imin;
+        const uint32_t wrapw = (jw.periodic == 1 && dw.pmin == dw.imin) ? (uint32_t)jw.pixels : 0u;
+
+        for (int64_t v = v0; v < vend; ++v) {
+            const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
+            // ---- load, quantize, park ---------------------------------------------------------------
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t e = 4 * (tid + 256 * r);                // element of the vtile
+                const Vec3Group g = vec3_load(a, sc, t * kVTile + e);
+                u32x4 q[3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float xv[3] = {g.x[c], g.y[c], g.z[c]};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float rq = quant_mul(xv[k], low[k], rdx[k]);
+                        if (__builtin_expect(__builtin_amdgcn_classf(rq, 0x90), 0)) rq = __fdiv_rn(__fsub_rn(xv[k], low[k]), dxq[k]);
+                        q[k][c] = g.valid ? (uint32_t)cvt_floor_i32(rq) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = q[k];
+            }
+            lds_barrier();
+            // ---- wave w packs component w and writes its words out (wave-local) ------------------------
+            if (okw) {
+                uint32_t* plane = lds + kw * kVPlane;
+                const int l = lane_id();
+                uint32_t qq[kGroup];
+#pragma unroll
+                for (int k8 = 0; k8 < kGroup / 4; ++k8) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(plane + l * kStride32 + 4 * k8);
+                    qq[4 * k8] = rr.x; qq[4 * k8 + 1] = rr.y; qq[4 * k8 + 2] = rr.z; qq[4 * k8 + 3] = rr.w;
+                }
+                const int64_t e0 = (int64_t)t * kVTile + kGroup * l;
+                if (wrapw == 0) {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) qq[i] -= iminw;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) { const uint32_t r2 = qq[i] - iminw; qq[i] = min(r2, r2 + wrapw); }
+                }
+                if (e0 + kGroup > jw.n) {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) if (e0 + i >= jw.n) qq[i] = 0;
+                }
+                // all 64 lanes have read their groups before any lane overwrites the plane with words
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pack_group32_switch(qq, bw, plane + l * bw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int64_t byte0 = (int64_t)t * (kVTile / 8) * bw;
+                int64_t nbytes_t = (int64_t)(kVTile / 8) * bw;
+                if (byte0 + nbytes_t > dw.nbytes) nbytes_t = dw.nbytes - byte0;
+                uint8_t* dst = (uint8_t*)jw.dst;
+                const int full = (int)(nbytes_t >> 4);
+                for (int c = l; c < full; c += 64)
+                    stg<u32x4>(dst + byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(plane + 4 * c));
+                const int rem = (int)(nbytes_t & 15);
+                if (l < rem) {
+                    const uint32_t w = plane[4 * full + (l >> 2)];
+                    stg<uint8_t>(dst + byte0 + 16 * (int64_t)full + l, (uint8_t)(w >> (8 * (l & 3))));
+                }
+            }
+            lds_barrier();
+        }
+        v0 = vend;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// minp.Reader.Vectors without the staging pass: the three streams of a sub-cell are unpacked vtile by vtile
+// and written straight into the AoS grid (dequantize, group.go:299-310; periodic fix-up, minp.go:188-196;
+// setSubCell).  32-bit streams only (bits <= 32, ring and minimum in int32: the NARROW class of
+// k_unpack_f32); anything else goes through the staging path.  HBM traffic: the streams + 12 B/particle
+// written, against streams + 12 B written + 12 B read + 12 B written of the staging path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restrict__ vec_out, const DevJob* __restrict__ jobs,
+                                                     int periodic, float L) {
+    constexpr int kLW = kTileD / 64 * 32 + 2;                     // 64-bit words of one component's vtile
+    constexpr int kNW = (kLW + 255) / 256;
+    static_assert(kTileD == kVTile, "the stream helpers are written for 2,048-element tiles");
+    __shared__ __attribute__((aligned(16))) uint64_t lw[3][kLW];
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)a.s3 * a.tiles_per_sc;
+    int64_t v0 = total * blockIdx.x / gridDim.x;
+    const int64_t v1 = total * (blockIdx.x + 1) / gridDim.x;
+    while (v0 < v1) {
+        const uint32_t sc = (uint32_t)(v0 / a.tiles_per_sc);
+        int64_t vend = (int64_t)(sc + 1) * a.tiles_per_sc;
+        if (vend > v1) vend = v1;
+        uint32_t b[3], mask[3], ka[3], kb[3];
+        int32_t mn[3], pix[3];
+        float low[3], dx[3];
+        StreamView sv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const DevJob jb = jobs[(int64_t)k * a.s3 + sc];
+            b[k] = (uint32_t)jb.bits;
+            mask[k] = b[k] == 0 ? 0u : (b[k] == 32 ? ~0u : ((1u << b[k]) - 1u));
+            mn[k] = (int32_t)jb.min; pix[k] = (int32_t)jb.pixels;
+            low[k] = jb.low; dx[k] = jb.dxq;
+            sv[k] = stream_view(jb, b[k]);
+            const uint64_t key = dither_key(jb.seed, jb.block, 0);   // element indices stay below 2^32
+            ka[k] = (uint32_t)key; kb[k] = (uint32_t)(key >> 32);
+        }
+        // the words of the next vtile are loaded into registers while the current one is extracted
+        uint64_t w[3][kNW];
+        {
+            const uint32_t t = (uint32_t)(v0 - (int64_t)sc * a.tiles_per_sc);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (b[k] != 0) load_tile_words<kNW>(w[k], sv[k], (int64_t)t * kVTile, b[k]);
+        }
+        for (int64_t v = v0; v < vend; ++v) {
+            const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (b[k] != 0) {
+                    stage_tile_words<kNW>(lw[k], w[k], b[k]);
+                    if (v + 1 < vend) load_tile_words<kNW>(w[k], sv[k], (int64_t)(t + 1) * kVTile, b[k]);
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t e = 4 * (tid + 256 * r);
+                const uint32_t j = t * kVTile + e;
+                if (j < a.gm.n_sub3) {
+                    sc_f32x4 o[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t val = b[k] == 0 ? 0u : extract32(reinterpret_cast<const uint32_t*>(lw[k]), e + c, b[k], mask[k]);
+                            int32_t q = mn[k] + (int32_t)val;                 // group.go:262
+                            if (q < 0) q += pix[k];                           // bound(buf, 0, pixels): FloatGroups are periodic
+                            else if (q >= pix[k]) q -= pix[k];
+                            const uint32_t z = dither_bits(j + c, ka[k], kb[k]);
+                            const double u = (double)z * (1.0 / 4294967296.0);
+                            const float x = __fadd_rn(__fmul_rn(dx[k], (float)__dadd_rn((double)q, u)), low[k]);   // group.go:308
+                            o[k][c] = wrap_once(x, L, periodic);
+                        }
+                    }
+                    const uint32_t i = particle_of(a.gm, sc * a.gm.n_sub3 + j);
+                    MNW_GLOBAL_SC sc_f32x4* p = (MNW_GLOBAL_SC sc_f32x4*)(vec_out + 3 * (int64_t)i);
+                    const sc_f32x4 q0 = {o[0].x, o[1].x, o[2].x, o[0].y}, q1 = {o[1].y, o[2].y, o[0].z, o[1].z},
+                                   q2 = {o[2].z, o[0].w, o[1].w, o[2].w};
+                    p[0] = q0; p[1] = q1; p[2] = q2;
+                }
+            }
+            lds_barrier();
+        }
+        v0 = vend;
+    }
+}
+
 static SubcellGeom make_geom(int64_t n_file, int64_t sub_cells) {
     SubcellGeom g;
     g.n_file = (uint32_t)n_file; g.sub_cells = (uint32_t)sub_cells; g.n_sub = (uint32_t)(n_file / sub_cells);
@@ -178,4 +484,29 @@ void launch_bounds3(hipStream_t s, int cus, const float* vec, int64_t n, uint32_
     hipLaunchKernelGGL(k_bounds3, dim3(subcell_grid(n / 4 + 1, cus)), dim3(256), 0, s, vec, n, keys);
 }
 
-}  // namespace mnw
+void launch_reduce_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, uint64_t* stats) {
+    Vec3Args a;
+    a.vec = vec; a.gm = make_geom(n_file, sub_cells);
+    a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
+    a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    hipLaunchKernelGGL(k_reduce_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats);
+}
+void launch_pack_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, const uint64_t* stats,
+                      Meta* meta) {
+    Vec3Args a;
+    a.vec = vec; a.gm = make_geom(n_file, sub_cells);
+    a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
+    a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    hipLaunchKernelGGL(k_pack_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats, meta);
+}
+int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
+    const int64_t n_sub = n_file / sub_cells, n3 = n_sub * n_sub * n_sub;
+    return sub_cells * sub_cells * sub_cells * ((n3 + kVTile - 1) / kVTile);
+}
+void launch_unpack_vec3(hipStream_t s, int grid, float* vec_out, int64_t n_file, int64_t sub_cells, const DevJob* jobs, int periodic, float L) {
+    Vec3Args a;
+    a.vec = vec_out; a.gm = make_geom(n_file, sub_cells);
+    a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
+    a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    hipLaunchKernelGGL(k_unpack_vec3, dim3(grid), dim3(256), 0, s, a, vec_out, jobs, periodic, L);
+}

@@ -190,3 +190,42 @@ def test_c4_shaped_file_cell(mnw, ctx2, torch_mod):
         torch.cuda.synchronize()
         assert [(m.min, m.bits, m.nbytes) for m in metas] == [(m.min, m.bits, m.nbytes) for m in metas2]
         assert torch.equal(first, packed)
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod, fused):
+    """n_sub and n_file multiples of four: mnw_vectors_encode reads the grid directly (k_reduce_vec3 + k_pack_vec3)
+    unless vec3_fused = 0; both must give the oracle's blocks.  Includes a partial last vtile (n_sub^3 = 13,824 =
+    6 * 2,048 + 1,536), a constant component (bits == 0) and a wrapped ring."""
+    from minnow_amd import minp
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(99)
+    nf, sub_cells, L = 48, 2, 250.0
+    g = make_vectors((0, 0, 0), L, nf)
+    pos = np.mod(g + 3.0 * rng.standard_normal(g.shape), L).astype(np.float32)
+    pos[pos >= np.float32(L)] = 0.0
+    pos[:, 1] = np.mod(1.0 + 0.5 * rng.standard_normal(nf ** 3), L).astype(np.float32)      # hugs the seam: periodicMin != 0
+    pos[:, 2] = np.float32(17.25)                                                            # constant: every block is 0 bits
+    with mnw.Context(0) as c:
+        c.set_option("vec3_fused", fused)
+        c.timing_enable(True)
+        _roundtrip(mnw, c, oracle, torch, dev, np.ascontiguousarray(pos), nf, sub_cells, 0.001, True, L)
+        ran = {k for k, v in c.timing_get().items() if v["launches"]}
+        assert ("k_pack_vec3" in ran) == bool(fused) and ("k_subcell_gather" in ran) == (not fused)
+        assert ("k_unpack_vec3" in ran) == bool(fused) and ("k_subcell_scatter" in ran) == (not fused)
+        # a NaN sends its block to the exact path: the fused kernels hand the whole call to the staging path
+        bad = pos.copy(); bad[12345, 0] = np.nan
+        c.timing_reset()
+        t = torch.from_numpy(bad).to(dev)
+        n_sub = nf // sub_cells
+        slot = (8 * n_sub ** 3 + 16 + 15) // 16 * 16
+        packed = torch.zeros(3 * sub_cells ** 3 * slot, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        metas, low, high, pixels = minp.vectors_encode(c, t.data_ptr(), nf, sub_cells, 0.001, True, L, packed.data_ptr(), slot)
+        torch.cuda.synchronize()
+        blocks, *_ = oracle.minp_vectors_encode(bad, nf, sub_cells, 0.001, True, L)
+        host = packed.cpu().numpy()
+        for b, (m, (omin, obits, odata)) in enumerate(zip(metas, blocks)):
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), b
+            assert host[b * slot: b * slot + m.nbytes].tobytes() == odata.tobytes(), b
