@@ -183,6 +183,25 @@ int mnw_subcell_gather(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int6
 int mnw_subcell_scatter(mnw_ctx *ctx, mnw_stream_t stream, const float *soa, int64_t n_file, int64_t sub_cells,
                         int periodic, float L, float *vec);
 
+/* ---- minh column transforms (go/minh/minh.go) ---------------------------------------------------
+ * minh.Writer.Block copies every FloatGroup column into a buffer, runs processFloatGroup on it and encodes
+ * the buffer (minh.go:128-135).  mnw_minh_process is that copy + processFloatGroup (139-149) for up to 64
+ * device columns per call: dst[i] = src[i], replaced by float32(math.Log10(float64(.))) if log != 0, then
+ * clamped: below low -> low, at or above high -> Nextafter32(high, -Inf).  src == dst is allowed.  The
+ * blocks are then encoded from dst with mnw_encode_blocks.  mnw_minh_unlog is the reader's
+ * float32(math.Pow(10, float64(x))) (minh.go:315-319) in place, after mnw_decode_blocks.  Enqueue only.
+ * Log10 / Pow are Go's portable algorithms restated (parity unpinned). */
+typedef struct mnw_minh_col {
+    const float *src;    /* device */
+    float *dst;          /* device (process: output; unlog: the column, in place; src is ignored) */
+    int64_t n;
+    float low, high;     /* Column.Low / Column.High (process only) */
+    int32_t log;         /* Column.Log */
+    int32_t reserved;
+} mnw_minh_col;
+int mnw_minh_process(mnw_ctx *ctx, mnw_stream_t stream, const mnw_minh_col *cols, int ncols);
+int mnw_minh_unlog(mnw_ctx *ctx, mnw_stream_t stream, const mnw_minh_col *cols, int ncols);
+
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */
 int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
@@ -208,7 +227,9 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_REDUCE_VEC3 11  /* minp vectors without staging: statistics of the three blocks of every sub-cell */
 #define MNW_K_PACK_VEC3   12  /* ... and their pack, straight from the array-of-structures grid */
 #define MNW_K_UNPACK_VEC3 13  /* minp vectors without staging: the three streams of a sub-cell into the grid */
-#define MNW_K_COUNT       14
+#define MNW_K_MINH_PROCESS 14 /* minh processFloatGroup over device columns */
+#define MNW_K_MINH_UNLOG  15  /* minh reader: 10^x */
+#define MNW_K_COUNT       16
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;

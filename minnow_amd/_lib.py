@@ -10,7 +10,7 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 14
+K_COUNT = 16
 
 
 class MnwError(RuntimeError):
@@ -36,6 +36,11 @@ class DecJobC(C.Structure):
 
 class BlockMetaC(C.Structure):
     _fields_ = [("min", C.c_int64), ("bits", C.c_int64), ("nbytes", C.c_int64), ("status", C.c_int64)]
+
+
+class MinhColC(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("low", C.c_float), ("high", C.c_float),
+                ("log", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KernelTimeC(C.Structure):
@@ -77,6 +82,8 @@ SIGNATURES = {
     "mnw_vectors_bounds": (_int, [_p, _p, _p, _i64, C.POINTER(_f32), C.POINTER(_f32)]),
     "mnw_subcell_gather": (_int, [_p, _p, _p, _i64, _i64, _p]),
     "mnw_subcell_scatter": (_int, [_p, _p, _p, _i64, _i64, _int, _f32, _p]),
+    "mnw_minh_process": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
+    "mnw_minh_unlog": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),

@@ -7,7 +7,7 @@ import ctypes as C
 from dataclasses import dataclass
 
 from . import _lib
-from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MnwError
+from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MinhColC, MnwError
 
 INT_GROUP = 10     # go/group.go:22
 FLOAT_GROUP = 11   # go/group.go:23
@@ -213,6 +213,17 @@ class Context:
 
     def subcell_scatter(self, soa_ptr, n_file, sub_cells, periodic, L, vec_ptr, stream=None):
         self._check(self._L.mnw_subcell_scatter(self._h, stream, soa_ptr, n_file, sub_cells, int(bool(periodic)), float(L), vec_ptr))
+
+    # -- minh column transforms (go/minh/minh.go:139-149, 315-319) -----------------------------
+    def minh_process(self, cols, stream=None):
+        """cols: (src_ptr, dst_ptr, n, low, high, log) per column: copy + processFloatGroup on the device"""
+        arr = (MinhColC * max(len(cols), 1))(*[MinhColC(s, d, n, lo, hi, int(bool(lg)), 0) for s, d, n, lo, hi, lg in cols])
+        self._check(self._L.mnw_minh_process(self._h, stream, arr, len(cols)))
+
+    def minh_unlog(self, cols, stream=None):
+        """cols: (ptr, n) per logarithmic column: x <- float32(10 ** float64(x)) in place"""
+        arr = (MinhColC * max(len(cols), 1))(*[MinhColC(None, d, n, 0.0, 0.0, 1, 0) for d, n in cols])
+        self._check(self._L.mnw_minh_unlog(self._h, stream, arr, len(cols)))
 
     def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
         self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))

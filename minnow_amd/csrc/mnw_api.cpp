@@ -34,6 +34,11 @@ void launch_reduce_vec3(hipStream_t, int, const float*, int64_t, int64_t, const 
 void launch_pack_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, const uint64_t*, Meta*);
 int64_t vec3_tiles(int64_t, int64_t);
 void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float);
+constexpr int kMinhBatch = 64;
+struct MinhCol { const float* src; float* dst; int64_t n; float low, high, high_below; int32_t xform; };
+struct MinhArgs { MinhCol col[kMinhBatch]; };
+void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
+void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -592,6 +597,8 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_REDUCE_VEC3: return "k_reduce_vec3";
         case MNW_K_PACK_VEC3: return "k_pack_vec3";
         case MNW_K_UNPACK_VEC3: return "k_unpack_vec3";
+        case MNW_K_MINH_PROCESS: return "k_minh_process";
+        case MNW_K_MINH_UNLOG: return "k_minh_unlog";
         default: return "";
     }
 }
@@ -1108,6 +1115,39 @@ int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int6
     HIPCHK(c, hipGetLastError());
     return MNW_OK;
 }
+
+// ---- minh column transforms (go/minh/minh.go:139-149, 315-319) ------------------------------------
+namespace {
+int minh_launch(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols, bool unlog) {
+    if (!c || ncols < 0 || (ncols > 0 && !cols)) return fail(c, MNW_E_ARG, "minh: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (int c0 = 0; c0 < ncols; c0 += mnw::kMinhBatch) {
+        mnw::MinhArgs a;
+        memset(&a, 0, sizeof a);
+        int m = 0;
+        int64_t max_n = 0;
+        for (int i = c0; i < ncols && m < mnw::kMinhBatch; ++i) {
+            const mnw_minh_col& col = cols[i];
+            if (col.n < 0 || (col.n > 0 && (!col.dst || (!unlog && !col.src)))) return fail(c, MNW_E_ARG, "minh: null pointer or negative length");
+            if (col.n == 0) continue;
+            mnw::MinhCol& d = a.col[m++];
+            d.src = unlog ? col.dst : col.src; d.dst = col.dst; d.n = col.n; d.low = col.low; d.high = col.high;
+            d.high_below = nextafterf(col.high, -INFINITY);       // math.Nextafter32(col.High, float32(math.Inf(-1)))
+            d.xform = unlog ? mnw::kXfLog10 : ((col.log ? mnw::kXfLog10 : 0) | mnw::kXfClamp);
+            if (col.n > max_n) max_n = col.n;
+        }
+        if (m == 0) continue;
+        if (unlog) { ScopedTimer t(c, s, MNW_K_MINH_UNLOG); mnw::launch_minh_unlog(s, c->cus, a, m, max_n); }
+        else { ScopedTimer t(c, s, MNW_K_MINH_PROCESS); mnw::launch_minh_process(s, c->cus, a, m, max_n); }
+        HIPCHK(c, hipGetLastError());
+    }
+    return MNW_OK;
+}
+}  // namespace
+
+int mnw_minh_process(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, false); }
+int mnw_minh_unlog(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, true); }
 
 // ---- raw bit.Array on device buffers ----------------------------------------------------------
 int mnw_pack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint64_t* x, int64_t n, int bits, uint8_t* out, int64_t cap) {

@@ -88,6 +88,137 @@ MNW_HD double go_log_frac(double x) {            // x in [0.5, 1)
     return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
 }
 
+// ---- Go's math.Log10 / math.Pow(10, y) for minh's logarithmic columns (go/minh/minh.go:141, 316) ----
+// Restated from the portable Go definitions (src/math: frexp.go, log.go, log10.go, exp.go, modf.go, ldexp.go,
+// pow.go).  Parity unpinned: there is no Go toolchain to compare with, and amd64 builds of Go use an assembly
+// Exp whose last float64 bit can differ.  The library is built with -ffp-contract=off: no operation below
+// may be fused.
+MNW_HD double go_frexp(double x, int* e) {       // any x
+    union { double d; uint64_t u; } c;
+    *e = 0;
+    if (x == 0.0 || x != x || x - x != 0.0) return x;          // 0, NaN, +-Inf
+    c.d = x;
+    if (((c.u >> 52) & 0x7ff) == 0) { x *= 4503599627370496.0; *e = -52; c.d = x; }   // subnormal: normalize
+    *e += (int)((c.u >> 52) & 0x7ff) - 1022;
+    c.u = (c.u & ~(0x7ffull << 52)) | (1022ull << 52);
+    return c.d;
+}
+
+MNW_HD double go_log(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01;
+    const double L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01;
+    const double L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01;
+    const double L7 = 1.479819860511658591e-01;
+    if (x != x || (x > 0 && x - x != 0.0)) return x;           // NaN, +Inf
+    if (x < 0) return __builtin_nan("");
+    if (x == 0) return -__builtin_inf();
+    int ki;
+    double f1 = go_frexp(x, &ki);
+    if (f1 < 0.70710678118654752440) { f1 *= 2; ki--; }
+    const double f = f1 - 1;
+    const double k = (double)ki;
+    const double s = f / (2 + f);
+    const double s2 = s * s;
+    const double s4 = s2 * s2;
+    const double t1 = s2 * (L1 + s4 * (L3 + s4 * (L5 + s4 * L7)));
+    const double t2 = s4 * (L2 + s4 * (L4 + s4 * L6));
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * Ln2Hi - ((hfsq - (s * (hfsq + R) + k * Ln2Lo)) - f);
+}
+
+MNW_HD double go_log10(double x) {               // log10.go: math.log2(x) * (Ln2 / Ln10)
+    int e;
+    const double frac = go_frexp(x, &e);
+    const double l2 = frac == 0.5 ? (double)(e - 1) : go_log(frac) * 1.44269504088896340736 + (double)e;
+    return l2 * 0.30102999566398119521;          // Ln2/Ln10 as an exact constant expression, rounded once
+}
+
+MNW_HD double go_ldexp(double frac, int exp) {
+    union { double d; uint64_t u; } c;
+    if (frac == 0 || frac != frac || frac - frac != 0.0) return frac;
+    int e = 0;
+    c.d = frac;
+    if (((c.u >> 52) & 0x7ff) == 0) { frac *= 4503599627370496.0; e = -52; c.d = frac; }   // normalize
+    exp += e;
+    exp += (int)((c.u >> 52) & 0x7ff) - 1023;
+    if (exp < -1075) return frac < 0 ? -0.0 : 0.0;
+    if (exp > 1023) return frac < 0 ? -__builtin_inf() : __builtin_inf();
+    double m = 1;
+    if (exp < -1022) { exp += 53; m = 1.0 / 9007199254740992.0; }      // denormal result: 2**-53
+    c.u &= ~(0x7ffull << 52);
+    c.u |= (uint64_t)(exp + 1023) << 52;
+    return m * c.d;
+}
+
+MNW_HD double go_exp(double x) {
+    const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    const double Log2e = 1.44269504088896338700e+00;
+    const double Overflow = 7.09782712893383973096e+02, Underflow = -7.45133219101941108420e+02;
+    const double NearZero = 1.0 / 268435456.0;   // 2**-28
+    const double P1 = 1.66666666666666657415e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05;
+    const double P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x || (x > 0 && x - x != 0.0)) return x;
+    if (x < 0 && x - x != 0.0) return 0;
+    if (x > Overflow) return __builtin_inf();
+    if (x < Underflow) return 0;
+    if (-NearZero < x && x < NearZero) return 1 + x;
+    int k = 0;
+    if (x < 0) k = (int)(Log2e * x - 0.5);
+    else if (x > 0) k = (int)(Log2e * x + 0.5);
+    const double hi = x - (double)k * Ln2Hi;
+    const double lo = (double)k * Ln2Lo;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1 - ((lo - (r * c) / (2 - c)) - hi);
+    return go_ldexp(y, k);
+}
+
+// math.Pow(10, y), pow.go with x == 10 (Frexp(10) = 0.625, 4)
+MNW_HD double go_pow10(double y) {
+    if (y == 0) return 1;
+    if (y == 1) return 10;
+    if (y != y) return y;
+    if (y - y != 0.0) return y > 0 ? __builtin_inf() : 0.0;      // +-Inf with |x| > 1
+    if (y == 0.5) return __builtin_sqrt(10.0);
+    if (y == -0.5) return 1 / __builtin_sqrt(10.0);
+    const double ay = y < 0 ? -y : y;
+    if (ay >= 9223372036854775808.0) return y > 0 ? __builtin_inf() : 0.0;
+    double yi = (double)(int64_t)ay;             // Modf of a non-negative value below 2^63: truncation
+    double yf = ay - yi;
+    double a1 = 1.0;
+    int ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5) { yf--; yi++; }
+        a1 = go_exp(yf * go_log(10.0));
+    }
+    double x1 = 0.625;
+    int xe = 4;
+    for (int64_t i = (int64_t)yi; i != 0; i >>= 1) {
+        if (xe < -4096 || 4096 < xe) { ae += xe; break; }        // catastrophic overflow
+        if (i & 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < .5) { x1 += x1; xe--; }
+    }
+    if (y < 0) { a1 = 1 / a1; ae = -ae; }
+    return go_ldexp(a1, ae);
+}
+
+// minh.processFloatGroup on one value (go/minh/minh.go:139-149)
+constexpr int kXfLog10 = 1;
+constexpr int kXfClamp = 2;
+MNW_HD float xf_apply(float x, int xform, float low, float high, float high_below) {
+    if (xform & kXfLog10) x = (float)go_log10((double)x);
+    if (xform & kXfClamp) {
+        if (x < low) x = low;
+        if (x >= high) x = high_below;           // math.Nextafter32(col.High, float32(math.Inf(-1)))
+    }
+    return x;
+}
+
 // bit.PrecisionNeeded (bit.go:19-21).  Returns -1 for max == 2^64-1, where Go computes
 // int(ceil(log2(0))) = int(-Inf): out of domain (MNW_E_DOMAIN).
 MNW_HD int precision_needed(uint64_t max) {

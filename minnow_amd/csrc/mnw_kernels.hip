@@ -1747,6 +1747,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict
 }
 
 #include "mnw_subcell.hip"
+#include "mnw_minh.hip"
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)

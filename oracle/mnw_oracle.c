@@ -511,3 +511,137 @@ float mnwo_nextafter32(float x, float y) {
     memcpy(&x, &u, 4);
     return x;
 }
+
+/* ---- minh column transforms ------------------------------------------------------------------- */
+/* src/math/log10.go: log10(x) = math.Log2(x) * (Ln2 / Ln10); the constant expression is exact, rounded once */
+double mnwo_go_log10(double x) {
+    static const double Ln2OverLn10 = 0.30102999566398119521;
+    return mnwo_go_log2(x) * Ln2OverLn10;
+}
+
+/* src/math/ldexp.go */
+static double go_ldexp(double frac, int exp) {
+    uint64_t u;
+    int e = 0;
+    double m = 1;
+    if (frac == 0 || isinf(frac) || isnan(frac)) return frac;
+    memcpy(&u, &frac, 8);
+    if (((u >> 52) & 0x7ff) == 0) { frac *= 4503599627370496.0; e = -52; memcpy(&u, &frac, 8); }   /* normalize */
+    exp += e;
+    exp += (int)((u >> 52) & 0x7ff) - 1023;
+    if (exp < -1075) return copysign(0.0, frac);
+    if (exp > 1023) return frac < 0 ? -INFINITY : INFINITY;
+    if (exp < -1022) { exp += 53; m = 1.0 / 9007199254740992.0; }
+    u &= ~(0x7ffull << 52);
+    u |= (uint64_t)(exp + 1023) << 52;
+    memcpy(&frac, &u, 8);
+    return m * frac;
+}
+
+/* src/math/exp.go (pure Go; FreeBSD e_exp.c) */
+static double go_exp(double x) {
+    static const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10;
+    static const double Log2e = 1.44269504088896338700e+00;
+    static const double Overflow = 7.09782712893383973096e+02, Underflow = -7.45133219101941108420e+02;
+    static const double NearZero = 1.0 / (1 << 28);
+    static const double P1 = 1.66666666666666657415e-01, P2 = -2.77777777770155933842e-03;
+    static const double P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06;
+    static const double P5 = 4.13813679705723846039e-08;
+    int k = 0;
+    double hi, lo, r, t, c, y;
+    if (isnan(x) || (isinf(x) && x > 0)) return x;
+    if (isinf(x)) return 0;
+    if (x > Overflow) return INFINITY;
+    if (x < Underflow) return 0;
+    if (-NearZero < x && x < NearZero) return 1 + x;
+    if (x < 0) k = (int)(Log2e * x - 0.5);
+    else if (x > 0) k = (int)(Log2e * x + 0.5);
+    hi = x - (double)k * Ln2Hi;
+    lo = (double)k * Ln2Lo;
+    r = hi - lo;
+    t = r * r;
+    c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    y = 1 - ((lo - (r * c) / (2 - c)) - hi);
+    return go_ldexp(y, k);
+}
+
+/* src/math/modf.go */
+static double go_modf(double f, double *frac) {
+    uint64_t x;
+    unsigned e;
+    double ip;
+    if (f < 1) {
+        if (f < 0) { ip = go_modf(-f, frac); *frac = -*frac; return -ip; }
+        if (f == 0) { *frac = f; return f; }
+        *frac = f;
+        return 0;
+    }
+    memcpy(&x, &f, 8);
+    e = (unsigned)((x >> 52) & 0x7ff) - 1023;
+    if (e < 64 - 12) x &= ~((1ull << (64 - 12 - e)) - 1);
+    memcpy(&ip, &x, 8);
+    *frac = f - ip;
+    return ip;
+}
+
+/* src/math/pow.go */
+double mnwo_go_pow(double x, double y) {
+    double yi, yf, a1 = 1.0, x1;
+    int ae = 0, xe;
+    int64_t i;
+    if (y == 0 || x == 1) return 1;
+    if (y == 1) return x;
+    if (isnan(x) || isnan(y)) return NAN;
+    if (x == 0) {
+        if (y < 0) { double t; if (go_modf(y, &t), t == 0 && ((int64_t)y & 1)) return copysign(INFINITY, x); return INFINITY; }
+        if (y > 0) { double t; if (go_modf(y, &t), t == 0 && ((int64_t)y & 1)) return x; return 0; }
+    }
+    if (isinf(y)) {
+        if (x == -1) return 1;
+        if ((fabs(x) < 1) == (y > 0)) return 0;
+        return INFINITY;
+    }
+    if (isinf(x)) {
+        if (x < 0) { double t; int odd = (go_modf(y, &t), t == 0 && ((int64_t)y & 1)); if (y < 0) return odd ? -0.0 : 0.0; return odd ? -INFINITY : INFINITY; }
+        return y < 0 ? 0 : INFINITY;
+    }
+    if (y == 0.5) return sqrt(x);
+    if (y == -0.5) return 1 / sqrt(x);
+    yi = go_modf(fabs(y), &yf);
+    if (yf != 0 && x < 0) return NAN;
+    if (yi >= 9223372036854775808.0) {
+        if (x == -1) return 1;
+        if ((fabs(x) < 1) == (y > 0)) return 0;
+        return INFINITY;
+    }
+    if (yf != 0) {
+        if (yf > 0.5) { yf--; yi++; }
+        a1 = go_exp(yf * go_log(x));
+    }
+    x1 = go_frexp(x, &xe);
+    for (i = (int64_t)yi; i != 0; i >>= 1) {
+        if (xe < -(1 << 12) || (1 << 12) < xe) { ae += xe; break; }
+        if (i & 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < .5) { x1 += x1; xe--; }
+    }
+    if (y < 0) { a1 = 1 / a1; ae = -ae; }
+    return go_ldexp(a1, ae);
+}
+
+/* go/minh/minh.go:139-149 */
+void mnwo_process_float_group(float *buf, int64_t n, int log, float low, float high) {
+    int64_t j;
+    for (j = 0; j < n; j++) {
+        if (log != 0) buf[j] = (float)mnwo_go_log10((double)buf[j]);
+        if (buf[j] < low) buf[j] = low;
+        if (buf[j] >= high) buf[j] = mnwo_nextafter32(high, -INFINITY);
+    }
+}
+
+/* go/minh/minh.go:315-319 */
+void mnwo_unlog(float *buf, int64_t n) {
+    int64_t i;
+    for (i = 0; i < n; i++) buf[i] = (float)mnwo_go_pow(10, (double)buf[i]);
+}

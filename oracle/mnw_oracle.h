@@ -115,6 +115,15 @@ void mnwo_periodic_fix(float *x, int64_t n, float L);
 /* math.Nextafter32(x, y) (Go src/math/nextafter.go), used by minp.go:94 */
 float mnwo_nextafter32(float x, float y);
 
+/* ---- minh column transforms (go/minh/minh.go) ----------------------------------------------
+ * processFloatGroup (minh.go:139-149), in place; Go's math.Log10 restated (log10.go, log.go, frexp.go). */
+void mnwo_process_float_group(float *buf, int64_t n, int log, float low, float high);
+/* the reader's float32(math.Pow(10, float64(x))) (minh.go:315-319), in place; Go's math.Pow / Exp / Ldexp /
+ * Modf restated from their portable definitions (pow.go, exp.go, ldexp.go, modf.go). */
+void mnwo_unlog(float *buf, int64_t n);
+double mnwo_go_log10(double x);
+double mnwo_go_pow(double x, double y);
+
 #ifdef __cplusplus
 }
 #endif

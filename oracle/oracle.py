@@ -63,6 +63,10 @@ def lib():
             "mnwo_bounds3": (None, [p, i64, p, p]),
             "mnwo_periodic_fix": (None, [p, i64, f32]),
             "mnwo_nextafter32": (f32, [f32, f32]),
+            "mnwo_process_float_group": (None, [p, i64, ci, f32, f32]),
+            "mnwo_unlog": (None, [p, i64]),
+            "mnwo_go_log10": (dbl, [dbl]),
+            "mnwo_go_pow": (dbl, [dbl, dbl]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -332,3 +336,24 @@ def minp_vectors_decode(blocks, n_file, sub_cells, mn, mx, pix, periodic, L, see
             bufs.append(x)
         set_sub_cell(out, bufs, sc, sub_cells, n_sub)
     return out
+
+
+# ---- minh column transforms (go/minh/minh.go:139-149, 315-319) --------------------------------------
+def process_float_group(x, log, low, high):
+    buf = np.array(x, dtype=np.float32, copy=True, order="C")
+    lib().mnwo_process_float_group(_ptr(buf), buf.size, int(bool(log)), float(np.float32(low)), float(np.float32(high)))
+    return buf
+
+
+def unlog(x):
+    buf = np.array(x, dtype=np.float32, copy=True, order="C")
+    lib().mnwo_unlog(_ptr(buf), buf.size)
+    return buf
+
+
+def go_log10(x):
+    return float(lib().mnwo_go_log10(float(x)))
+
+
+def go_pow(x, y):
+    return float(lib().mnwo_go_pow(float(x), float(y)))

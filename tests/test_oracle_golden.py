@@ -241,3 +241,29 @@ def test_minp_nextafter32_and_limits(oracle):
     assert mx[0] == np.nextafter(np.float32(4), np.float32(8)) and mx[1] == np.nextafter(np.float32(-2), np.float32(-4))
     mn, mx = oracle.minp_limits(vec, True, 100.0)
     assert list(mn) == [0, 0, 0] and list(mx) == [100, 100, 100]
+
+
+# ---- minh column transforms (go/minh/minh.go:139-149, 315-319) ---------------------------------------
+def test_minh_process_float_group_semantics(oracle):
+    x = np.array([0.0, -1.0, 1e8, 1e16, 3e13, np.inf], dtype=np.float32)
+    y = oracle.process_float_group(x, True, 8.0, 16.0)
+    below_high = np.nextafter(np.float32(16), np.float32(0))
+    assert y[0] == 8.0 and np.isnan(y[1]) and y[2] == 8.0 and y[3] == below_high and y[5] == below_high
+    assert abs(float(y[4]) - 13.477121) < 1e-5
+    z = oracle.process_float_group(np.array([99, 100, 150, 200, 201], dtype=np.float32), False, 100.0, 200.0)
+    assert list(z) == [100, 100, 150, np.nextafter(np.float32(200), np.float32(0)), np.nextafter(np.float32(200), np.float32(0))]
+
+
+def test_minh_go_log10_pow_restatement_is_plausible(oracle):
+    """Not a pin (no Go here): the restated algorithms must at least be accurate to an ulp or so
+    and exact where Go's are exact by construction."""
+    import math
+    rng = np.random.default_rng(9)
+    for x in 10 ** rng.uniform(-300, 300, 4000):
+        assert abs(oracle.go_log10(x) - math.log10(x)) <= 4e-16 * max(1.0, abs(math.log10(x)))
+    for k in range(-20, 21):
+        assert oracle.go_log10(2.0 ** k) == k * 0.30102999566398119521          # log2 of a power of two is exact
+    assert oracle.go_pow(10, 0) == 1 and oracle.go_pow(10, 1) == 10 and oracle.go_pow(10, 2) == 100 and oracle.go_pow(10, 0.5) == math.sqrt(10)
+    for y in rng.uniform(-300, 300, 4000):
+        assert abs(oracle.go_pow(10, y) / 10 ** y - 1) < 2e-15
+    assert oracle.go_pow(10, float("inf")) == float("inf") and oracle.go_pow(10, float("-inf")) == 0 and math.isnan(oracle.go_pow(10, float("nan")))
