@@ -258,6 +258,16 @@ int ensure_dev(mnw_ctx* c, void** p, size_t* cap, size_t need) {
     return MNW_OK;
 }
 
+// Wait for a stream whose work is expected to finish within microseconds: poll before blocking (a blocking
+// hipStreamSynchronize wakes the thread up 10-20 us after the last kernel has finished).
+hipError_t wait_stream(hipStream_t s) {
+    for (int i = 0; i < 20000; ++i) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+    return hipStreamSynchronize(s);
+}
+
 hipEvent_t get_event(mnw_ctx* c) {
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -799,7 +809,7 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     JobSlot* sl = c->pend;
     c->pend = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, wait_stream(s));
     const int njobs = (int)c->pend_jobs.size();
     if (c->pend_mode != 0 && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
         // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
@@ -1009,7 +1019,7 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
         { ScopedTimer t(c, s, MNW_K_REDUCE_VEC3); mnw::launch_reduce_vec3(s, gr, vec, n_file, sub_cells, sl->d_jobs, sl->d_stats); }
         { ScopedTimer t(c, s, MNW_K_PACK_VEC3); mnw::launch_pack_vec3(s, gp, vec, n_file, sub_cells, sl->d_jobs, sl->d_stats, sl->d_meta); }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, wait_stream(s));
         bool exact = false;
         int first = MNW_OK;
         for (int64_t b = 0; b < 3 * s3; ++b) {
