@@ -683,3 +683,15 @@ def test_c4_particle_snapshot_blocks(mnw, ctx, oracle, torch_mod):
         if per:
             d = np.minimum(d, 250.0 - d)
         assert d.max() <= float(dxq) * 1.01 + 1e-3, (k, d.max())
+
+
+def test_randomised_differential_short(mnw):
+    """a few seconds of tests/fuzz_parity.py (random blocks, parameters, batch shapes and encode structures against the
+    oracle; the long runs are done by hand: `python tests/fuzz_parity.py 150 1` = 112,627 blocks without a mismatch in
+    round 1)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_parity
+    cases, blocks = fuzz_parity.run(6.0, 2024)
+    assert cases > 50 and blocks > 200
