@@ -244,6 +244,8 @@ const char *mnw_kernel_name(int kernel_id);
  * fused: 1 = float batches run as one persistent launch (k_encode_f32); 0 (default) = see single_read.
  * single_read: 1 (default) = a float batch whose blocks all have at most 2^22 elements is encoded by
  *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
+ * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
+ *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.
  * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels
  *        when the geometry allows (n_sub and n_file multiples of four); 0 = always gather into the staging
  *        buffer first and run the block encoder on that.

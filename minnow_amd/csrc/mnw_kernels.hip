@@ -1036,6 +1036,11 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
     }
 }
 
+// round sizes of the weighted item hand-out, in quarters of the grid (see k_encode_reg_f32)
+constexpr int kRounds = 14;
+__constant__ int kRoundQuarters[kRounds] = {4, 4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 2, 4};      // 14 / 12 / 11 / 10 items per cycle
+// (measured against 14/13/12/11, 14/14/12/11 and 14/11/10/9: within 1 % at 1e8 elements, best at 1e9)
+
 #ifdef MNW_STAMPS
 __device__ unsigned long long g_slow_sweeps = 0;
 #endif
@@ -1045,7 +1050,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                                                                  ItemRec* __restrict__ recs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
                                                                  uint32_t* __restrict__ abort_host,
-                                                                 Meta* __restrict__ meta) {
+                                                                 Meta* __restrict__ meta, int weighted) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufR];
     __shared__ float red[4][kThreadsR / 64];
     __shared__ int redbad[kThreadsR / 64];
@@ -1084,7 +1089,26 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         }
     };
 
-    int64_t it = blockIdx.x;
+    // Item hand-out.  Rounds: in round k the workgroups [0, size_k) take the items base_k + w.  With `weighted`
+    // the round sizes cycle through kRoundQuarters (in quarters of the grid), so that per cycle the four
+    // quarters of the grid take 14 / 12 / 11 / 10 items: the hardware favours the oldest waves of a CU and a
+    // CU's four workgroups come from the four quarters of the grid in dispatch order, which makes the last
+    // quarter run at 70 % of the speed of the first (measured: 109 / 125 / 142 / 154 us for twelve items
+    // each).  No two partial rounds are adjacent, so two consecutive items of a workgroup are at least a
+    // whole grid apart and the header's argument holds unchanged.  (Handing the items out with a counter
+    // instead puts a returning atomic on wave 0's path every trip and measured 15 % slower overall.)
+    const int unit = weighted ? (int)gridDim.x / 4 : (int)gridDim.x;
+    int round = 0;
+    int64_t round_base = 0;
+    auto next_item = [&]() -> int64_t {           // the workgroup's item after the one in (round, round_base)
+        for (;;) {
+            round_base += (int64_t)(weighted ? kRoundQuarters[round] : 1) * unit;
+            round = round + 1 == kRounds ? 0 : round + 1;
+            if (round_base >= total_items) return total_items;
+            if ((int)blockIdx.x < (weighted ? kRoundQuarters[round] : 1) * unit) return round_base + blockIdx.x;
+        }
+    };
+    int64_t it = blockIdx.x;                      // round 0 is a full one
     bool have_cur = it < total_items;
     if (have_cur) { locate(it); issue(); }
     bool have_prev = false;
@@ -1097,10 +1121,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         const float xh = cxh;
         const float* const sx = cx + cbase;
         const int64_t srem = cn - cbase;                 // elements of item i (>= kItem: a full one)
-        // The next item.  (Handing the items out with a counter instead would even out the workgroups -- the
-        // hardware favours the oldest waves of a CU, so the youngest workgroups finish ~40% after the oldest
-        // -- but the returning atomic sits on wave 0's path every trip and measured 15% slower overall.)
-        const int64_t nit = it + gridDim.x;
+        const int64_t nit = have_cur ? next_item() : total_items;
         const bool have_next = have_cur && nit < total_items;
         // where the next item lives: scalar loads, started long before they are needed
         if (have_next) locate(nit);
@@ -1777,9 +1798,9 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta) {
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted) {
     hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag,
-                       abort_host, meta);
+                       abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0);
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }

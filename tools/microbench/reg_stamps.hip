@@ -42,9 +42,9 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(dj, hj.data(), sizeof(DevJob) * nj, hipMemcpyHostToDevice)); CHK(hipMemset(recs, 0, sizeof(ItemRec) * items)); CHK(hipMemset(ab, 0, 128));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     uint32_t gen = 1;
-    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm); }
+    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip); }
     CHK(hipDeviceSynchronize()); CHK(hipMemset(sb, 0, 8 * 8 * 4096));
-    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
     float ms; CHK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> h(8 * grid); CHK(hipMemcpy(h.data(), sb, 8 * 8 * grid, hipMemcpyDeviceToHost));
     Meta m0; CHK(hipMemcpy(&m0, dm, sizeof m0, hipMemcpyDeviceToHost)); uint32_t abv; CHK(hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost));
@@ -63,6 +63,8 @@ int main(int argc, char** argv) {
       for (int w = 0; w < grid; ++w) { smax = std::max(smax, ha[2 * w] - t0); emin = std::min(emin, ha[2 * w + 1] - t0); emax = std::max(emax, ha[2 * w + 1] - t0); }
       for (int x = 0; x < 8; ++x) { double se = 0; int c = 0; unsigned long long mx = 0, mn = ~0ull; for (int w = x; w < grid; w += 8) { se += ha[2 * w + 1] - t0; ++c; mx = std::max(mx, ha[2 * w + 1] - t0); mn = std::min(mn, ha[2 * w + 1] - t0); }
         printf("    w%%8=%d: end mean %.1f min %.1f max %.1f us\n", x, se / c / 100.0, mn / 100.0, mx / 100.0); }
+      for (int qd = 0; qd < 8; ++qd) { double se = 0, sl = 0; int c = 0; for (int w = qd * grid / 8; w < (qd + 1) * grid / 8; ++w) { se += ha[2 * w + 1] - t0; sl += ha[2 * w + 1] - ha[2 * w]; ++c; }
+        printf("    ids [%d,%d): end mean %.1f us, lifetime mean %.1f us\n", qd * grid / 8, (qd + 1) * grid / 8, se / c / 100.0, sl / c / 100.0); }
       int hist[16] = {0}; for (int w = 0; w < grid; ++w) { int b = (int)((ha[2 * w + 1] - t0) / 1000); if (b > 15) b = 15; hist[b]++; }
       printf("    end-time histogram (10 us bins):"); for (int b = 0; b < 16; ++b) printf(" %d", hist[b]); printf("\n");
       printf("    first 64 WG end times:"); for (int w = 0; w < 64; ++w) printf(" %.0f", (ha[2 * w + 1] - t0) / 100.0); printf("\n");
