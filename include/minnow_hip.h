@@ -246,6 +246,8 @@ const char *mnw_kernel_name(int kernel_id);
  *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
  * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
  *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.
+ * reg_test_drop_item: test hook (default -1): the single-read kernel never publishes the statistics of that item, so
+ *        the launch must give up after its 50 ms bound and the host must rerun the batch through reduce + pack.
  * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels
  *        when the geometry allows (n_sub and n_file multiples of four); 0 = always gather into the staging
  *        buffer first and run the block encoder on that.

@@ -20,7 +20,7 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t);
 size_t item_rec_bytes();
 int reg_max_items_per_block();
 int64_t reg_item_elems();
@@ -133,6 +133,7 @@ struct mnw_ctx {
     int64_t group_bytes = 1ll << 40;   // two-kernel path: all blocks of a batch in one reduce + one pack launch
     int grid_cap = 0;
     int fused = 0;               // float encode as one persistent launch per batch (k_encode_f32): opt-in, see DESIGN.md
+    int64_t reg_drop_item = -1;  // TEST HOOK: the single-read kernel never publishes this item's record -> bounded wait, abort, host fallback
     int reg_weighted = 1;        // single read: weighted item hand-out (see k_encode_reg_f32)
     int vec3_fused = 1;          // minp vectors: reduce + pack straight from the AoS grid when the geometry allows
     int single_read = 1;         // float encode through k_encode_reg_f32 (block read once) whenever the batch is eligible
@@ -502,7 +503,7 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
         // the weighted hand-out only when the grid is the full co-resident one (four workgroups on every CU)
         mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
-                                   sl->d_meta, grid == c->cus * 4 ? c->reg_weighted : 0);
+                                   sl->d_meta, grid == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item);
     }
     HIPCHK(c, hipGetLastError());
     return MNW_OK;
@@ -661,6 +662,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_weighted")) { c->reg_weighted = value != 0; return MNW_OK; }
+    if (!strcmp(name, "reg_test_drop_item")) { c->reg_drop_item = value; return MNW_OK; }
     if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
     return fail(c, MNW_E_ARG, "unknown option");
 }

@@ -934,8 +934,8 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 // owner is past it) or in (m, m+G): its owner handles the items congruent to k mod G in increasing
 // order, is at worst blocked on an item m' >= m of that residue class and has published m'+G already;
 // k < m+G <= m'+G and k = m' (mod G) give k <= m', so k's record is out.  The host only sends blocks
-// of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; spins are bounded and a
-// timeout aborts the launch (the host then reruns the batch through the two-kernel path).
+// of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; a wait is bounded (50 ms),
+// after which the launch aborts and the host reruns the batch through the two-kernel path.
 // HBM traffic = algorithmic bytes: 4 B/element read + b/8 B/element written.
 // ------------------------------------------------------------------------------------------------
 constexpr int kThreadsR = 256;
@@ -1004,6 +1004,7 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
     const int nitems = (int)items_of(jobs[j].n);
     const ItemRec* r0 = recs + jobs[j].tile0;
     uint32_t spins = 0;
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();      // 100 MHz
     for (;;) {
         uint32_t v[4] = {0, 0, 0, 0};
         uint32_t bad = 0, missing = 0;
@@ -1026,7 +1027,9 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
         __builtin_amdgcn_s_sleep(4);
         ++spins;
         if ((spins & 15) == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
-        if (spins > (1u << 18)) {
+        // 50 ms without the block completing: its other workgroups are not running (something else holds part
+        // of the GPU), give the batch back to the host
+        if ((spins & 15) == 0 && __builtin_amdgcn_s_memrealtime() - t_start > 5000000ull) {
             if (lane_id() == 0) {
                 __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word
@@ -1050,7 +1053,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                                                                  ItemRec* __restrict__ recs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
                                                                  uint32_t* __restrict__ abort_host,
-                                                                 Meta* __restrict__ meta, int weighted) {
+                                                                 Meta* __restrict__ meta, int weighted, int64_t test_drop_item) {
+    // (test_drop_item: test hook, normally -1 -- the record of that item is never published, so its block can
+    // never complete and the launch has to take its bounded-wait exit)
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufR];
     __shared__ float red[4][kThreadsR / 64];
     __shared__ int redbad[kThreadsR / 64];
@@ -1209,7 +1214,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             }
         }
         lds_barrier();
-        if (have_cur && tid < 4) {
+        if (have_cur && tid < 4 && sit != test_drop_item) {
             // publish the item's record (wave 0, lanes 0..3: one 8-byte sc1 store each)
             float a = red[0][0], b2 = red[1][0], c2 = red[2][0], dd = red[3][0];
             int bd = redbad[0];
@@ -1798,9 +1803,9 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted) {
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t test_drop_item) {
     hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag,
-                       abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0);
+                       abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }
