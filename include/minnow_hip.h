@@ -178,6 +178,15 @@ int mnw_vectors_decode(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *src, in
 /* bounds() of minp.go:290-300 over vec[n][3] (device): per-component minimum and maximum (host outputs).
  * The caller applies Nextafter32(max, 2*max) as minp.Writer.Vectors does (minp.go:92-95).  Synchronous. */
 int mnw_vectors_bounds(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int64_t n, float min[3], float max[3]);
+/* Host-pointer forms of the two calls above: vec / vec_out are host arrays ([][3]float32 slices), the blocks live in
+ * a host buffer of 3*sub_cells^3 slots of slot_bytes (a multiple of 16) each.  Synchronous; nothing retained. */
+int mnw_vectors_encode_host(mnw_ctx *ctx, const float *vec, int64_t n_file, int64_t sub_cells,
+                            const float low[3], const float high[3], const int64_t pixels[3],
+                            uint8_t *out, int64_t slot_bytes, mnw_block_meta *meta);
+int mnw_vectors_decode_host(mnw_ctx *ctx, const uint8_t *in, int64_t slot_bytes, const mnw_block_meta *meta,
+                            int64_t n_file, int64_t sub_cells, const float low[3], const float high[3],
+                            const int64_t pixels[3], int periodic, float L, uint64_t seed, uint64_t first_block,
+                            float *vec_out);
 /* The two layout passes alone (device buffers of 3*n_file^3 floats; soa is [k][sc][j]); enqueue only. */
 int mnw_subcell_gather(mnw_ctx *ctx, mnw_stream_t stream, const float *vec, int64_t n_file, int64_t sub_cells, float *soa);
 int mnw_subcell_scatter(mnw_ctx *ctx, mnw_stream_t stream, const float *soa, int64_t n_file, int64_t sub_cells,

@@ -79,6 +79,10 @@ SIGNATURES = {
                                   C.POINTER(BlockMetaC)]),
     "mnw_vectors_decode": (_int, [_p, _p, _p, _i64, C.POINTER(BlockMetaC), _i64, _i64, C.POINTER(_f32), C.POINTER(_f32),
                                   C.POINTER(_i64), _int, _f32, _u64, _u64, _p]),
+    "mnw_vectors_encode_host": (_int, [_p, _p, _i64, _i64, C.POINTER(_f32), C.POINTER(_f32), C.POINTER(_i64), _p, _i64,
+                                       C.POINTER(BlockMetaC)]),
+    "mnw_vectors_decode_host": (_int, [_p, _p, _i64, C.POINTER(BlockMetaC), _i64, _i64, C.POINTER(_f32), C.POINTER(_f32),
+                                       C.POINTER(_i64), _int, _f32, _u64, _u64, _p]),
     "mnw_vectors_bounds": (_int, [_p, _p, _p, _i64, C.POINTER(_f32), C.POINTER(_f32)]),
     "mnw_subcell_gather": (_int, [_p, _p, _p, _i64, _i64, _p]),
     "mnw_subcell_scatter": (_int, [_p, _p, _p, _i64, _i64, _int, _f32, _p]),

@@ -1351,4 +1351,51 @@ int mnw_float_decode(mnw_ctx* c, const uint8_t* in, int64_t in_len, int64_t min,
     return decode_host(c, MNW_FLOAT_GROUP, in, in_len, min, bits, low, high, pixels, periodic, seed, block, n, out);
 }
 
+// ---- minp vectors, host-pointer forms (what the cgo shim over Go slices binds) -----------------------
+// vec: [n_file^3][3] float32 on the host.  out: 3*sub_cells^3 slots of slot_bytes each on the host (block b at
+// out + b*slot_bytes, meta[b].nbytes bytes valid).  Crosses the host link twice; see DESIGN.md section 6.
+int mnw_vectors_encode_host(mnw_ctx* c, const float* vec, int64_t n_file, int64_t sub_cells, const float low[3], const float high[3],
+                            const int64_t pixels[3], uint8_t* out, int64_t slot_bytes, mnw_block_meta* meta) {
+    int rc = vectors_check(c, n_file, sub_cells, "vectors: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!vec || !out || !meta || slot_bytes < 0 || (slot_bytes & 15)) return fail(c, MNW_E_ARG, "vectors: null pointer or slot_bytes not a multiple of 16");
+    const int64_t n = n_file * n_file * n_file, nb = 3 * sub_cells * sub_cells * sub_cells;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = stage_in(c, vec, (size_t)n * 12);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)nb * (size_t)slot_bytes + 16);
+    if (rc) return rc;
+    rc = mnw_vectors_encode(c, c->stream, (const float*)c->d_in, n_file, sub_cells, low, high, pixels, (uint8_t*)c->d_out, slot_bytes, meta);
+    if (rc) return rc;
+    for (int64_t b = 0; b < nb; ++b)
+        if (meta[b].nbytes > 0)
+            HIPCHK(c, hipMemcpyAsync(out + b * slot_bytes, (const uint8_t*)c->d_out + b * slot_bytes, (size_t)meta[b].nbytes,
+                                     hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
+int mnw_vectors_decode_host(mnw_ctx* c, const uint8_t* in, int64_t slot_bytes, const mnw_block_meta* meta, int64_t n_file,
+                            int64_t sub_cells, const float low[3], const float high[3], const int64_t pixels[3], int periodic, float L,
+                            uint64_t seed, uint64_t first_block, float* vec_out) {
+    int rc = vectors_check(c, n_file, sub_cells, "vectors: n_file must be a positive multiple of sub_cells");
+    if (rc) return rc;
+    if (!in || !vec_out || !meta || slot_bytes < 0 || (slot_bytes & 15)) return fail(c, MNW_E_ARG, "vectors: null pointer or slot_bytes not a multiple of 16");
+    const int64_t n = n_file * n_file * n_file, nb = 3 * sub_cells * sub_cells * sub_cells;
+    HIPCHK(c, hipSetDevice(c->device));
+    rc = ensure_dev(c, &c->d_in, &c->cap_in, (size_t)nb * (size_t)slot_bytes + 16);
+    if (rc) return rc;
+    for (int64_t b = 0; b < nb; ++b)
+        if (meta[b].nbytes > 0)
+            HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in + b * slot_bytes, in + b * slot_bytes, (size_t)meta[b].nbytes, hipMemcpyHostToDevice, c->stream));
+    rc = ensure_dev(c, &c->d_out, &c->cap_out, (size_t)n * 12);
+    if (rc) return rc;
+    rc = mnw_vectors_decode(c, c->stream, (const uint8_t*)c->d_in, slot_bytes, meta, n_file, sub_cells, low, high, pixels, periodic, L, seed,
+                            first_block, (float*)c->d_out);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(vec_out, c->d_out, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
 }  // extern "C"

@@ -229,3 +229,34 @@ def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod
         for b, (m, (omin, obits, odata)) in enumerate(zip(metas, blocks)):
             assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), b
             assert host[b * slot: b * slot + m.nbytes].tobytes() == odata.tobytes(), b
+
+
+def test_vectors_host_pointer_forms(mnw, oracle):
+    """mnw_vectors_encode_host / _decode_host: numpy arrays standing in for the Go slices of minp.Writer.Vectors"""
+    import ctypes as C
+    from minnow_amd import _lib
+    L_ = _lib.lib()
+    rng = np.random.default_rng(55)
+    nf, sub_cells, L, dx = 16, 2, 100.0, 0.1
+    vec = np.ascontiguousarray(np.mod(make_vectors((0, 0, 0), L, nf) + rng.standard_normal((nf ** 3, 3)), L).astype(np.float32))
+    vec[vec >= np.float32(L)] = 0.0
+    n_sub = nf // sub_cells
+    nb = 3 * sub_cells ** 3
+    slot = (4 * n_sub ** 3 + 15) // 16 * 16
+    out = np.zeros(nb * slot, dtype=np.uint8)
+    blocks, omn, omx, opix = oracle.minp_vectors_encode(vec, nf, sub_cells, dx, True, L)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    i3 = lambda v: (C.c_int64 * 3)(*[int(x) for x in v])
+    meta = (_lib.BlockMetaC * nb)()
+    with mnw.Context(0) as c:
+        rc = L_.mnw_vectors_encode_host(c.handle, vec.ctypes.data, nf, sub_cells, f3(omn), f3(omx), i3(opix), out.ctypes.data, slot, meta)
+        assert rc == 0
+        for b, (omin, obits, odata) in enumerate(blocks):
+            assert (meta[b].min, meta[b].bits, meta[b].nbytes, meta[b].status) == (omin, obits, odata.size, 0)
+            assert out[b * slot: b * slot + odata.size].tobytes() == odata.tobytes()
+        back = np.zeros_like(vec)
+        rc = L_.mnw_vectors_decode_host(c.handle, out.ctypes.data, slot, meta, nf, sub_cells, f3(omn), f3(omx), i3(opix), 1, L, 9, 4,
+                                        back.ctypes.data)
+        assert rc == 0
+    ref = oracle.minp_vectors_decode(blocks, nf, sub_cells, omn, omx, opix, True, L, seed=9, first_block=4)
+    assert np.array_equal(back, ref)
