@@ -207,22 +207,49 @@ __global__ __launch_bounds__(256, 4) void k_reduce_vec3(Vec3Args a, const DevJob
         float xh[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) xh[k] = jobs[k * a.s3 + sc].xh;
-        FStat st[3];
+        // four statistics per component; three-input min / max over pairs of particles, one v_cmp_class for NaN / Inf
+        float mn[3], mx[3], mxlo[3], mnhi[3];
+        bool nonfinite = false;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) st[k] = FStat{INFINITY, -INFINITY, -INFINITY, INFINITY, false};
-        for (int64_t v = v0; v < vend; ++v) {
+        for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; mxlo[k] = -INFINITY; mnhi[k] = INFINITY; }
+        auto fold = [&](const Vec3Group& g) {
+            if (!g.valid) return;
+#pragma unroll
+            for (int c = 0; c < 4; c += 2) {
+                const float v0[3] = {g.x[c], g.y[c], g.z[c]}, v1[3] = {g.x[c + 1], g.y[c + 1], g.z[c + 1]};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    nonfinite |= __builtin_amdgcn_classf(v0[k], 0x207) | __builtin_amdgcn_classf(v1[k], 0x207);
+                    mn[k] = min3_raw(mn[k], v0[k], v1[k]);
+                    mx[k] = max3_raw(mx[k], v0[k], v1[k]);
+                    const bool l0 = v0[k] < xh[k], l1 = v1[k] < xh[k];
+                    mxlo[k] = max3_raw(mxlo[k], l0 ? v0[k] : -INFINITY, l1 ? v1[k] : -INFINITY);
+                    mnhi[k] = min3_raw(mnhi[k], l0 ? INFINITY : v0[k], l1 ? INFINITY : v1[k]);
+                }
+            }
+        };
+        int64_t v = v0;
+        for (; v + 1 < vend; v += 2) {                       // two vtiles (twelve 16-byte loads per lane) in flight
+            const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
+            Vec3Group g[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = vec3_load(a, sc, (t + (r >> 1)) * kVTile + 4 * (tid + 256 * (r & 1)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fold(g[r]);
+        }
+        for (; v < vend; ++v) {
             const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
             Vec3Group g[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) g[r] = vec3_load(a, sc, t * kVTile + 4 * (tid + 256 * r));
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (g[r].valid) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { fstat_add(st[0], g[r].x[c], xh[0]); fstat_add(st[1], g[r].y[c], xh[1]); fstat_add(st[2], g[r].z[c], xh[2]); }
-                }
-            }
+            for (int r = 0; r < 2; ++r) fold(g[r]);
         }
+        // (a NaN or an infinity anywhere in the run flags all three blocks: they then take the exact path, which
+        // is always right, only slower)
+        FStat st[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) st[k] = FStat{mn[k], mx[k], mxlo[k], mnhi[k], nonfinite};
         // fold the run into the three blocks' stat lines
         __syncthreads();
 #pragma unroll
@@ -302,13 +329,20 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
         const uint32_t iminw = (uint32_t)(int32_t)dw.imin;
         const uint32_t wrapw = (jw.periodic == 1 && dw.pmin == dw.imin) ? (uint32_t)jw.pixels : 0u;
 
+        // the next vtile's loads are issued as soon as the current one is parked: they fly during the pack
+        Vec3Group gl[2];
+        {
+            const uint32_t t = (uint32_t)(v0 - (int64_t)sc * a.tiles_per_sc);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) gl[r] = vec3_load(a, sc, t * kVTile + 4 * (tid + 256 * r));
+        }
         for (int64_t v = v0; v < vend; ++v) {
             const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
-            // ---- load, quantize, park ---------------------------------------------------------------
+            // ---- quantize, park ---------------------------------------------------------------------
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint32_t e = 4 * (tid + 256 * r);                // element of the vtile
-                const Vec3Group g = vec3_load(a, sc, t * kVTile + e);
+                const Vec3Group g = gl[r];
                 u32x4 q[3];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -322,6 +356,10 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) *reinterpret_cast<u32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = q[k];
+            }
+            if (v + 1 < vend) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) gl[r] = vec3_load(a, sc, (t + 1) * kVTile + 4 * (tid + 256 * r));
             }
             lds_barrier();
             // ---- wave w packs component w and writes its words out (wave-local) ------------------------
