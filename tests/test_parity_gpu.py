@@ -734,3 +734,46 @@ def test_randomised_differential_short(mnw):
     import fuzz_parity
     cases, blocks = fuzz_parity.run(6.0, 2024)
     assert cases > 50 and blocks > 200
+
+
+def test_many_small_blocks_in_one_batch(mnw, ctx, oracle, torch_mod):
+    """3,000 blocks of 1..20,000 elements (and a few empty ones) in one call: partial items only or mostly, several
+    items of different blocks per workgroup trip, int and float mixed"""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(314)
+    low, high, pixels = 0.0, 250.0, 250000
+    sizes = rng.integers(1, 20000, 3000)
+    sizes[::97] = 0
+    sizes[1::211] = 8192
+    xs, jobs, keep = [], [], []
+    total = int(sizes.sum()) + 4 * len(sizes) + 16            # blocks start on multiples of four elements
+    big_f = torch.from_numpy(np.mod(125 + 30 * rng.standard_normal(total), 250.0).astype(np.float32)).to(dev)
+    big_i = torch.from_numpy(rng.integers(-5000, 5000, total).astype(np.int64)).to(dev)
+    hf, hi = big_f.cpu().numpy(), big_i.cpu().numpy()
+    out = torch.zeros(int(8 * sizes.sum() + 32 * len(sizes)), dtype=torch.uint8, device=dev)
+    off = ooff = 0
+    for k, n in enumerate(sizes):
+        n = int(n)
+        a0 = (off + 3) // 4 * 4                      # float blocks start 16-byte aligned
+        cap = (8 * n + 31) // 16 * 16
+        if k % 5 == 4:
+            jobs.append(mnw.EncJob(big_i.data_ptr() + 8 * a0, out.data_ptr() + ooff, n, cap, mnw.INT_GROUP))
+            xs.append(("i", hi[a0:a0 + n]))
+        else:
+            jobs.append(mnw.EncJob(big_f.data_ptr() + 4 * a0, out.data_ptr() + ooff, n, cap, mnw.FLOAT_GROUP, low, high, pixels, 1))
+            xs.append(("f", hf[a0:a0 + n]))
+        keep.append((ooff, cap))
+        off = a0 + n
+        ooff += cap
+    torch.cuda.synchronize()
+    metas = ctx.encode_blocks(jobs)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for (kind, x), m, (o0, cap) in zip(xs, metas, keep):
+        if x.size == 0:
+            assert (m.bits, m.nbytes, m.status) == (0, 0, 0)
+            continue
+        omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False) if kind == "f" else oracle.int_encode(x, literal=False)
+        assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+        assert host[o0: o0 + m.nbytes].tobytes() == odata.tobytes()
