@@ -903,9 +903,11 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 // single-read float32 encode (k_encode_reg_f32): the block is read ONCE.
 //
 // An item = 8,192 consecutive elements of one block = 32 values per lane of a 256-lane workgroup.
-// Workgroup w takes items w, w+G, w+2G, ... of the batch-wide item numbering and always has two of them
-// on chip: item i in the registers e[] (loaded, or still in flight from HBM) and item i-1 parked as raw
-// floats in LDS, its statistics PUBLISHED and waiting for the rest of its block.  Per loop trip:
+// The items of the batch are dealt out in rounds (round k: workgroups [0, size_k) take items base_k + w;
+// all rounds are the whole grid G, or -- weighted hand-out, see the kernel -- some are a prefix of it), so
+// every workgroup takes its items in increasing order.  A workgroup always has two of them on chip: item i
+// in the registers e[] (loaded, or still in flight from HBM) and item i-1 parked as raw floats in LDS, its
+// statistics PUBLISHED and waiting for the rest of its block.  Per loop trip:
 //
 //   1. start the loads of the records of item i-1's block (see 3)
 //   2. fold item i's floats into the four statistics of k_reduce_f32 and publish them as one 32-byte
@@ -928,14 +930,17 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 // Memory operations of a wave complete in issue order, hence: the record loads are issued before
 // anything else of the trip, every barrier is the LDS-only one, and the kernel must not spill.
 //
-// No deadlock if every block has at most G items and all G workgroups are resident: a workgroup
-// publishes item i before it waits for item i-1's block and never waits before publishing.  Let m be
-// the smallest item any workgroup is blocked on.  An item k of m's block is either < m (published: its
-// owner is past it) or in (m, m+G): its owner handles the items congruent to k mod G in increasing
-// order, is at worst blocked on an item m' >= m of that residue class and has published m'+G already;
-// k < m+G <= m'+G and k = m' (mod G) give k <= m', so k's record is out.  The host only sends blocks
-// of at most min(G, kMaxSweep) items here and sizes G from the occupancy query; a wait is bounded (50 ms),
-// after which the launch aborts and the host reruns the batch through the two-kernel path.
+// No deadlock if every block has at most G items and all G workgroups are resident.  A workgroup
+// publishes item i before it waits for item i-1's block and never waits before publishing.  Suppose
+// nothing moves any more and let u be the lowest item whose record is not out.  Its owner X has not
+// reached it, so X is blocked: it holds a parked item p and a published current item c, u is X's next
+// item or a later one, and X waits for an unpublished item w of p's block; w >= u as u is the lowest.
+// So p's block contains p and w >= u, i.e. it has more than u - p items.  But X's items p, c, u are taken
+// in three different rounds, so u - p is at least the size of two consecutive rounds; no two partial
+// rounds are adjacent, hence u - p >= G: a block of at most G items cannot contain both.  The host only
+// sends blocks of at most min(G, kMaxSweep) items here and sizes G from the occupancy query.  Should the
+// premise fail (another kernel holding part of the GPU), a wait is bounded (50 ms), after which the launch
+// gives up and the host reruns the batch through the two-kernel path (tests: reg_test_drop_item).
 // HBM traffic = algorithmic bytes: 4 B/element read + b/8 B/element written.
 // ------------------------------------------------------------------------------------------------
 constexpr int kThreadsR = 256;
