@@ -59,7 +59,7 @@ for k, d in per.items():
 
 res = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py "
-              "--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing`, %s; FETCH_SIZE doubled (gfx950 reports half "
+              "--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --big-particles 0`, %s; FETCH_SIZE doubled (gfx950 reports half "
               "the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM), WRITE_SIZE as is; both counters are in KiB" % tag,
     "kernels": kern,
 }
