@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNW_ABI_VERSION 1
+#define MNW_ABI_VERSION 2   /* 2: xform field in mnw_enc_job / mnw_dec_job */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MNW_OK            0
@@ -104,6 +104,8 @@ int mnw_float_decode(mnw_ctx *ctx, const uint8_t *in, int64_t in_len, int64_t mi
  * packed stream of block k is written at dst (16-byte aligned, capacity cap bytes); its exact
  * length comes back in meta[k].nbytes, which is what blockIndex.addBlock receives
  * (block_index.go:16-23). */
+#define MNW_XF_LOG10 1   /* Column.Log != 0 */
+#define MNW_XF_CLAMP 2   /* x < Low -> Low, x >= High -> Nextafter32(High, -Inf): always set by minh */
 typedef struct mnw_enc_job {
     const void *src;     /* device: float32[n] (MNW_FLOAT_GROUP) or int64[n] (MNW_INT_GROUP) */
     void *dst;           /* device: packed stream, 16-byte aligned */
@@ -113,6 +115,9 @@ typedef struct mnw_enc_job {
     float low, high;     /* float groups: floatGroup.low / high */
     int32_t kind;        /* MNW_INT_GROUP or MNW_FLOAT_GROUP */
     int32_t periodic;    /* float groups: floatGroup.periodic (1 from Writer.FloatGroup, writer.go:74) */
+    int32_t xform;       /* float groups: MNW_XF_* -- minh.processFloatGroup (go/minh/minh.go:139-149) applied to every
+                          * value before anything else looks at it, limits = low / high; 0 for plain minnow groups */
+    int32_t reserved;
 } mnw_enc_job;
 
 typedef struct mnw_dec_job {
@@ -128,6 +133,9 @@ typedef struct mnw_dec_job {
     int32_t periodic;
     uint64_t seed;       /* dither key (float groups) */
     uint64_t block;      /* dither key: block index */
+    int32_t xform;       /* float groups: MNW_XF_LOG10 = float32(math.Pow(10, float64(x))) on every decoded value
+                          * (minh.Reader.FloatBlock, go/minh/minh.go:315-319); 0 otherwise */
+    int32_t reserved;
 } mnw_dec_job;
 
 typedef struct mnw_block_meta {
@@ -210,6 +218,10 @@ typedef struct mnw_minh_col {
 } mnw_minh_col;
 int mnw_minh_process(mnw_ctx *ctx, mnw_stream_t stream, const mnw_minh_col *cols, int ncols);
 int mnw_minh_unlog(mnw_ctx *ctx, mnw_stream_t stream, const mnw_minh_col *cols, int ncols);
+/* Diagnostic: compares the kernels' fast forms of float32(Log10(float64(x))) (which = 0) and float32(Pow(10, float64(y)))
+ * (which = 1) with the exact restatement on the float32 bit patterns [first, first + count): out[0] = mismatches,
+ * out[1] = inputs outside the fast path's domain.  Synchronous.  The GPU tests run it over all 2^32 patterns. */
+int mnw_minh_selftest(mnw_ctx *ctx, int which, uint64_t first, uint64_t count, uint64_t out[2]);
 
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */

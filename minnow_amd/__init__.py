@@ -17,6 +17,8 @@ from ._lib import (  # noqa: F401
 )
 from .codec import (  # noqa: F401
     FLOAT_GROUP,
+    XF_CLAMP,
+    XF_LOG10,
     INT_GROUP,
     BlockMeta,
     Context,
@@ -27,6 +29,6 @@ from .groups import BitArray, FloatGroupCodec, IntGroupCodec  # noqa: F401
 
 __all__ = [
     "MnwError", "array_bytes", "device_count", "float_group_pixels", "lib", "lib_path",
-    "precision_needed", "Context", "EncJob", "DecJob", "BlockMeta", "INT_GROUP", "FLOAT_GROUP",
+    "precision_needed", "Context", "EncJob", "DecJob", "BlockMeta", "INT_GROUP", "FLOAT_GROUP", "XF_CLAMP", "XF_LOG10",
     "BitArray", "IntGroupCodec", "FloatGroupCodec",
 ]

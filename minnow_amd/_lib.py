@@ -24,14 +24,14 @@ class MnwError(RuntimeError):
 class EncJobC(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("cap", C.c_int64),
                 ("pixels", C.c_int64), ("low", C.c_float), ("high", C.c_float),
-                ("kind", C.c_int32), ("periodic", C.c_int32)]
+                ("kind", C.c_int32), ("periodic", C.c_int32), ("xform", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DecJobC(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("src_len", C.c_int64),
                 ("min", C.c_int64), ("bits", C.c_int64), ("pixels", C.c_int64),
                 ("low", C.c_float), ("high", C.c_float), ("kind", C.c_int32), ("periodic", C.c_int32),
-                ("seed", C.c_uint64), ("block", C.c_uint64)]
+                ("seed", C.c_uint64), ("block", C.c_uint64), ("xform", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BlockMetaC(C.Structure):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "mnw_subcell_scatter": (_int, [_p, _p, _p, _i64, _i64, _int, _f32, _p]),
     "mnw_minh_process": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
     "mnw_minh_unlog": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
+    "mnw_minh_selftest": (_int, [_p, _int, _u64, _u64, C.POINTER(_u64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),

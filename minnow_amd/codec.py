@@ -11,12 +11,14 @@ from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MinhColC, MnwError
 
 INT_GROUP = 10     # go/group.go:22
 FLOAT_GROUP = 11   # go/group.go:23
+XF_LOG10 = 1       # minh Column.Log (go/minh/minh.go:141, 316)
+XF_CLAMP = 2       # minh's clamp into [Low, High) (go/minh/minh.go:142-147)
 
 
 _META_DTYPE = [("min", "<i8"), ("bits", "<i8"), ("nbytes", "<i8"), ("status", "<i8")]
 _DEC_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("n", "<i8"), ("src_len", "<i8"), ("min", "<i8"), ("bits", "<i8"),
               ("pixels", "<i8"), ("low", "<f4"), ("high", "<f4"), ("kind", "<i4"), ("periodic", "<i4"),
-              ("seed", "<u8"), ("block", "<u8")]
+              ("seed", "<u8"), ("block", "<u8"), ("xform", "<i4"), ("reserved", "<i4")]
 
 
 @dataclass
@@ -31,6 +33,7 @@ class EncJob:
     high: float = 0.0
     pixels: int = 0
     periodic: int = 1      # Writer.FloatGroup hard-codes periodic = true (writer.go:74)
+    xform: int = 0         # XF_LOG10 | XF_CLAMP: minh.processFloatGroup on the way in (go/minh/minh.go:139-149)
 
 
 @dataclass
@@ -49,6 +52,7 @@ class DecJob:
     periodic: int = 1
     seed: int = 0
     block: int = 0
+    xform: int = 0         # XF_LOG10: 10^x on the way out (go/minh/minh.go:315-319)
 
 
 @dataclass
@@ -109,7 +113,7 @@ class Context:
             return jobs
         arr = (EncJobC * max(len(jobs), 1))()
         for i, j in enumerate(jobs):
-            arr[i] = EncJobC(j.src, j.dst, j.n, j.cap, j.pixels, j.low, j.high, j.kind, j.periodic)
+            arr[i] = EncJobC(j.src, j.dst, j.n, j.cap, j.pixels, j.low, j.high, j.kind, j.periodic, getattr(j, 'xform', 0), 0)
         arr._n = len(jobs)
         return arr
 
@@ -122,7 +126,7 @@ class Context:
         arr = (DecJobC * max(len(jobs), 1))()
         for i, j in enumerate(jobs):
             arr[i] = DecJobC(j.src, j.dst, j.n, j.src_len, j.min, j.bits, j.pixels, j.low, j.high,
-                             j.kind, j.periodic, j.seed, j.block)
+                             j.kind, j.periodic, j.seed, j.block, getattr(j, 'xform', 0), 0)
         arr._n = len(jobs)
         return arr
 

@@ -20,9 +20,10 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int);
 size_t item_rec_bytes();
 int reg_max_items_per_block();
+int encode_reg_f32_xf_blocks_per_cu();
 int64_t reg_item_elems();
 int encode_reg_f32_blocks_per_cu();
 void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
@@ -39,6 +40,7 @@ struct MinhCol { const float* src; float* dst; int64_t n; float low, high, high_
 struct MinhArgs { MinhCol col[kMinhBatch]; };
 void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
+void launch_minh_selftest(hipStream_t, int, uint64_t, uint64_t, unsigned long long*);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -117,6 +119,11 @@ struct mnw_ctx {
     uint32_t* d_bkeys = nullptr;  // 8 words: bounds keys
     uint32_t* h_bkeys = nullptr;  // pinned
 
+    // minh value transforms for the encode paths that do not apply them at load time (two-pass, fused, exact):
+    // the processed copy of the block, like minh.buf (go/minh/minh.go:128-133)
+    size_t cap_xf = 0;
+    float* d_xf = nullptr;
+
     // exact path scratch
     size_t cap_q = 0;
     int64_t* d_q = nullptr;
@@ -137,7 +144,8 @@ struct mnw_ctx {
     int reg_weighted = 1;        // single read: weighted item hand-out (see k_encode_reg_f32)
     int vec3_fused = 1;          // minp vectors: reduce + pack straight from the AoS grid when the geometry allows
     int single_read = 1;         // float encode through k_encode_reg_f32 (block read once) whenever the batch is eligible
-    int reg_blocks_per_cu = 0;   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
+    int reg_blocks_per_cu = 0;
+    int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
     void* d_recs = nullptr;      // single read: one published statistics record per item (grow-only)
     size_t cap_recs = 0;
@@ -365,6 +373,8 @@ void fill_enc(DevJob& d, const mnw_enc_job& j) {
             memo.valid = true;
         }
         d.dxq = memo.dxq; d.rdx = memo.rdx; d.xh = memo.xh;
+        d.xform = j.xform & (mnw::kXfLog10 | mnw::kXfClamp);
+        d.high_below = nextafterf(j.high, -INFINITY);
     }
 }
 
@@ -439,15 +449,61 @@ int launch_encode_fused(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int 
     return MNW_OK;
 }
 
+// The encode structures other than the single-read kernel do not apply minh's value transform at load time:
+// for them the float jobs [0, nfloat) of the slot that carry one are processed into a staging copy first (the
+// reference's own data flow: minh.buf, minh.go:128-133) and then encoded from there as plain blocks.
+int stage_xforms(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat) {
+    size_t total = 0;
+    for (int k = 0; k < nfloat; ++k)
+        if (sl->h_jobs[k].xform) total += ((size_t)sl->h_jobs[k].n + 3) / 4 * 4;
+    if (total == 0) return MNW_OK;
+    void* p = c->d_xf;
+    int rc = ensure_dev(c, &p, &c->cap_xf, total * sizeof(float));
+    c->d_xf = (float*)p;
+    if (rc) return rc;
+    size_t off = 0;
+    mnw::MinhArgs a;
+    int m = 0;
+    int64_t max_n = 0;
+    auto flush = [&]() {
+        if (m == 0) return;
+        { ScopedTimer t(c, s, MNW_K_MINH_PROCESS); mnw::launch_minh_process(s, c->cus, a, m, max_n); }
+        m = 0; max_n = 0;
+    };
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < nfloat; ++k) {
+        DevJob& d = sl->h_jobs[k];
+        if (!d.xform) continue;
+        if (d.n > 0) {
+            mnw::MinhCol& col = a.col[m++];
+            col.src = (const float*)d.src; col.dst = c->d_xf + off; col.n = d.n;
+            col.low = d.low; col.high = d.high; col.high_below = d.high_below; col.xform = d.xform;
+            if (d.n > max_n) max_n = d.n;
+            d.src = c->d_xf + off;
+            off += ((size_t)d.n + 3) / 4 * 4;
+        }
+        d.xform = 0;
+        if (m == mnw::kMinhBatch) flush();
+    }
+    flush();
+    HIPCHK(c, hipGetLastError());
+    return MNW_OK;
+}
+
 // Single-read float encode (k_encode_reg_f32) for the float jobs [0, nfloat) of the slot.  Only legal
 // when every block has at most `grid` items (see the kernel's header); returns 1 if not eligible.
 int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
     if (c->reg_blocks_per_cu == 0) {
         int occ = mnw::encode_reg_f32_blocks_per_cu();
         c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);     // 256-thread workgroups, 36 KB LDS: four per CU
+        occ = mnw::encode_reg_f32_xf_blocks_per_cu();
+        c->reg_xf_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);  // the instantiation with the value transform (2.5 KB more LDS)
     }
-    if (c->reg_blocks_per_cu < 1) return 1;
-    int grid = c->cus * c->reg_blocks_per_cu;
+    int any_xform = 0;
+    for (int k = 0; k < nfloat; ++k) any_xform |= sl->h_jobs[k].xform;
+    const int per_cu = any_xform ? c->reg_xf_blocks_per_cu : c->reg_blocks_per_cu;
+    if (per_cu < 1) return 1;
+    int grid = c->cus * per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
     const int max_items = grid < mnw::reg_max_items_per_block() ? grid : mnw::reg_max_items_per_block();
     const int64_t item = mnw::reg_item_elems();
@@ -503,7 +559,7 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
         // the weighted hand-out only when the grid is the full co-resident one (four workgroups on every CU)
         mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
-                                   sl->d_meta, grid == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item);
+                                   sl->d_meta, grid == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item, any_xform);
     }
     HIPCHK(c, hipGetLastError());
     return MNW_OK;
@@ -537,7 +593,23 @@ int encode_one_sync(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, int mode,
 
 // floatGroup.writeData for a block whose periodicMin depends on element order: the literal sequence
 // of group.go:312-327 on the GPU (quantize -> sequential periodicMin -> bound -> intGroup path).
-int encode_exact_float(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job, Meta* out) {
+int encode_exact_float(mnw_ctx* c, hipStream_t s, const mnw_enc_job& job_in, Meta* out) {
+    mnw_enc_job job = job_in;
+    if (job.xform & (mnw::kXfLog10 | mnw::kXfClamp)) {
+        // minh's value transform first (all kernels of the batch have finished: the staging copy is free)
+        void* p = c->d_xf;
+        int rx = ensure_dev(c, &p, &c->cap_xf, ((size_t)job.n + 4) * sizeof(float));
+        c->d_xf = (float*)p;
+        if (rx) return rx;
+        mnw::MinhArgs a;
+        memset(&a, 0, sizeof a);
+        a.col[0].src = (const float*)job.src; a.col[0].dst = c->d_xf; a.col[0].n = job.n;
+        a.col[0].low = job.low; a.col[0].high = job.high; a.col[0].high_below = nextafterf(job.high, -INFINITY);
+        a.col[0].xform = job.xform & (mnw::kXfLog10 | mnw::kXfClamp);
+        { ScopedTimer t(c, s, MNW_K_MINH_PROCESS); mnw::launch_minh_process(s, c->cus, a, 1, job.n); }
+        job.src = c->d_xf;
+        job.xform = 0;
+    }
     int rc = ensure_dev(c, (void**)&c->d_q, &c->cap_q, (size_t)job.n * 8);
     if (rc) return rc;
     if (!c->d_state) HIPCHK(c, hipMalloc((void**)&c->d_state, 4 * sizeof(int64_t)));
@@ -648,6 +720,7 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_state) hipFree(c->d_state);
     if (c->d_recs) hipFree(c->d_recs);
     if (c->d_soa) hipFree(c->d_soa);
+    if (c->d_xf) hipFree(c->d_xf);
     if (c->d_bkeys) hipFree(c->d_bkeys);
     if (c->h_bkeys) hipHostFree(c->h_bkeys);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -786,6 +859,11 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
             else if (rc == MNW_OK) c->pend_mode = 2;
             else return rc;
         }
+        if (rc != MNW_OK) {
+            // not the single-read kernel: minh value transforms are applied in a pass of their own first
+            int rs = stage_xforms(c, sl, s, nfloat);
+            if (rs) return rs;
+        }
         if (rc == MNW_OK) {
             // launched above
         } else if (fused) {
@@ -832,7 +910,9 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
             }
             g0 = g1;
         }
-        int rc = prepare_slot(c, sl, s, c->pend_nfloat, true);
+        int rc = stage_xforms(c, sl, s, c->pend_nfloat);
+        if (rc) return rc;
+        rc = prepare_slot(c, sl, s, c->pend_nfloat, true);
         if (rc) return rc;
         rc = launch_encode_range(c, sl, s, 0, c->pend_nfloat, MNW_FLOAT_GROUP);
         if (rc) return rc;
@@ -919,6 +999,26 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
         else { ScopedTimer t(c, s, MNW_K_UNPACK_I64); mnw::launch_unpack_i64(s, grid, sl->d_jobs + j0, j1 - j0, tiles); }
     }
     HIPCHK(c, hipGetLastError());
+    // minh's logarithmic columns: 10^x on the decoded values (go/minh/minh.go:315-319), a pass over the output
+    {
+        mnw::MinhArgs a;
+        memset(&a, 0, sizeof a);
+        int m = 0;
+        int64_t max_n = 0;
+        for (int i = 0; i < njobs; ++i) {
+            const mnw_dec_job& j = jobs[i];
+            if (!(j.xform & MNW_XF_LOG10) || j.kind != MNW_FLOAT_GROUP || j.n == 0) continue;
+            mnw::MinhCol& col = a.col[m++];
+            col.src = (const float*)j.dst; col.dst = (float*)j.dst; col.n = j.n; col.xform = mnw::kXfLog10;
+            if (j.n > max_n) max_n = j.n;
+            if (m == mnw::kMinhBatch) {
+                { ScopedTimer t(c, s, MNW_K_MINH_UNLOG); mnw::launch_minh_unlog(s, c->cus, a, m, max_n); }
+                m = 0; max_n = 0;
+            }
+        }
+        if (m) { ScopedTimer t(c, s, MNW_K_MINH_UNLOG); mnw::launch_minh_unlog(s, c->cus, a, m, max_n); }
+        HIPCHK(c, hipGetLastError());
+    }
     return release_slot(c, sl, s);
 }
 
@@ -1160,6 +1260,22 @@ int minh_launch(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int n
     return MNW_OK;
 }
 }  // namespace
+
+int mnw_minh_selftest(mnw_ctx* c, int which, uint64_t first, uint64_t count, uint64_t out[2]) {
+    if (!c || !out || which < 0 || which > 1) return fail(c, MNW_E_ARG, "selftest: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, 16));
+    HIPCHK(c, hipMemsetAsync(d, 0, 16, c->stream));
+    mnw::launch_minh_selftest(c->stream, which, first, count, d);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(c, MNW_E_HIP, "selftest", e);
+    out[0] = h[0]; out[1] = h[1];
+    return MNW_OK;
+}
 
 int mnw_minh_process(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, false); }
 int mnw_minh_unlog(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, true); }

@@ -37,6 +37,9 @@ struct DevJob {
     int32_t periodic;
     int32_t bits;        // decode / explicit pack
     int32_t mode;        // kModeStats: width from the reduce pass; kModeExplicit: (min,bits) given
+    int32_t xform;       // kXfLog10 | kXfClamp: minh's processFloatGroup on every value before it is looked at (encode);
+                         // kXfLog10: 10^x on every value after the dequantize (decode)
+    float high_below;    // Nextafter32(high, -Inf): what the clamp maps x >= high to
 };
 
 constexpr int kModeStats = 0;

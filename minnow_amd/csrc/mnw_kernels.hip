@@ -115,6 +115,8 @@ __device__ __forceinline__ float quant_floor(float x, float low, float dx) {
     return floorf(__fdiv_rn(__fsub_rn(x, low), dx));
 }
 
+#include "mnw_gomath_fast.h"
+
 // ------------------------------------------------------------------------------------------------
 // reduce pass, float32 blocks.
 // q(x) = floor(fl(fl(x-low)/dx)) is monotone non-decreasing in x for dx > 0 (every step -- rounded
@@ -1053,6 +1055,11 @@ __constant__ int kRoundQuarters[kRounds] = {4, 4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 
 __device__ unsigned long long g_slow_sweeps = 0;
 #endif
 
+// XF: the batch has jobs with a minh value transform (DevJob.xform).  A separate instantiation: the plain kernel has
+// no scalar or vector register to spare, and carrying the transform's code and state cost it 6 %.  (The XF one
+// spills ~30 registers at four workgroups per CU and is still faster that way than at three without spills:
+// 5.8 vs 6.8 ms for the 24 float columns of tools/bench_c3.py.)
+template <bool XF>
 __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
                                                                  int64_t total_items, const int* __restrict__ item_job,
                                                                  ItemRec* __restrict__ recs,
@@ -1067,6 +1074,10 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     __shared__ uint32_t swv[4][kThreadsR / 64];
     __shared__ uint32_t swf[kThreadsR / 64];
     __shared__ uint64_t shared_slot;
+    // tables of the fast log10 (minh transforms): 2.5 KB of LDS in the XF instantiation, 8 bytes in the plain one
+    __shared__ typename std::conditional<XF, FastTables, double>::type ftab_s;
+    FastTables* const ftab_p = XF ? reinterpret_cast<FastTables*>(&ftab_s) : nullptr;
+    if (XF) fast_tables_load(ftab_p);
     constexpr int kV = kItem / (4 * kThreadsR);        // 16-byte loads per lane per item (8)
     constexpr int kW = kThreadsR / 64;
     const int tid = threadIdx.x;
@@ -1079,12 +1090,14 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     int64_t cbase = 0, cn = 0;
     const float* cx = nullptr;
     float cxh = 0.0f;
+    int cxf = 0;                // minh value transform of the item's job (0: none)
     auto locate = [&](int64_t t) {
         cj = item_job[t];
         cbase = (t - jobs[cj].tile0) * kItem;
         cn = jobs[cj].n;
         cx = (const float*)jobs[cj].src;
         cxh = jobs[cj].xh;
+        if (XF) cxf = jobs[cj].xform;
     };
     auto issue = [&]() {
         // (a block's last, partial item is not held in registers: its statistics and its parked copy are
@@ -1129,6 +1142,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         const int sj = cj;
         const int64_t sbase = cbase, sit = it;
         const float xh = cxh;
+        const int sxf = XF ? cxf : 0;
+        // (the transform's limits are fetched from the job record where they are used: nothing more is carried
+        // across the trip -- the kernel has no scalar or vector register to spare)
         const float* const sx = cx + cbase;
         const int64_t srem = cn - cbase;                 // elements of item i (>= kItem: a full one)
         const int64_t nit = have_cur ? next_item() : total_items;
@@ -1157,6 +1173,30 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             float mn = INFINITY, mx = -INFINITY, mxlo = -INFINITY, mnhi = INFINITY;
             bool nonfinite = false;
             if (srem >= kItem) {
+                if (sxf) {
+                    const float sxlow = jobs[sj].low, sxhigh = jobs[sj].high, sxhb = jobs[sj].high_below;
+                    // minh.processFloatGroup (minh.go:139-149) on the values as they arrive: what is parked, reduced
+                    // and packed below is the processed column, as if it had been encoded from minh.buf.  The
+                    // logarithm goes through its fast form; if that could not decide some value's float32 rounding
+                    // (a few in a million) the wave redoes its vectors from memory with the exact form.
+                    bool amb = false;
+#pragma unroll
+                    for (int k = 0; k < kV; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float xv = __uint_as_float(e[k][c]);
+                            if (sxf & kXfLog10) xv = go_log10_f32_try(xv, ftab_p, amb);
+                            if (sxf & kXfClamp) { if (xv < sxlow) xv = sxlow; if (xv >= sxhigh) xv = sxhb; }
+                            e[k][c] = __float_as_uint(xv);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);           // one 16-byte vector at a time: bounds the float64 temporaries
+                    }
+                    if (__builtin_expect(__any(amb), 0)) {
+                        const int t = opaque_tid();
+#pragma unroll
+                        for (int k = 0; k < kV; ++k) e[k] = xf_apply_exact4(sx + k * (4 * kThreadsR) + 4 * t, sxf, sxlow, sxhigh, sxhb);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < kV; ++k) {
 #pragma unroll
@@ -1173,7 +1213,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             } else {
 #pragma unroll 1
                 for (int i = tid; i < (int)srem; i += kThreadsR) {
-                    const float x0 = ldg<float>(sx + i);
+                    float x0 = ldg<float>(sx + i);
+                    if (sxf) x0 = xf_apply_fast(x0, sxf, jobs[sj].low, jobs[sj].high, jobs[sj].high_below, ftab_p);
                     nonfinite |= __builtin_amdgcn_classf(x0, 0x207);
                     mn = fminf(mn, x0); mx = fmaxf(mx, x0);
                     if (x0 < xh) mxlo = fmaxf(mxlo, x0); else mnhi = fminf(mnhi, x0);
@@ -1348,7 +1389,11 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             } else {
 #pragma unroll 1
                 for (int i = tid; i < kItem; i += kThreadsR)
-                    lds[stage32_idx(i)] = i < (int)srem ? ldg<uint32_t>(sx + i) : 0u;
+                {
+                    float xv = i < (int)srem ? ldg<float>(sx + i) : 0.0f;
+                    if (sxf && i < (int)srem) xv = xf_apply_fast(xv, sxf, jobs[sj].low, jobs[sj].high, jobs[sj].high_below, ftab_p);
+                    lds[stage32_idx(i)] = __float_as_uint(xv);
+                }
             }
             if (have_next) issue();
             MNW_STAMP(5)      // park + next loads issued
@@ -1808,16 +1853,26 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t test_drop_item) {
-    hipLaunchKernelGGL(k_encode_reg_f32, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen, abort_flag,
-                       abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t test_drop_item,
+                           int any_xform) {
+    if (any_xform)
+        hipLaunchKernelGGL(k_encode_reg_f32<true>, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
+                           abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
+    else
+        hipLaunchKernelGGL(k_encode_reg_f32<false>, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
+                           abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }
 int64_t reg_item_elems() { return kItem; }
 int encode_reg_f32_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32, kThreadsR, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<false>, kThreadsR, 0) != hipSuccess) return 0;
+    return n;
+}
+int encode_reg_f32_xf_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<true>, kThreadsR, 0) != hipSuccess) return 0;
     return n;
 }
 int encode_f32_blocks_per_cu() {

@@ -6,6 +6,34 @@
 // from Go's portable definitions) makes them VALU bound.
 // (This file is included by mnw_kernels.hip, inside namespace mnw.)
 
+// self-test: which = 0: log10, 1: pow10.  Compares the fast and the exact form for the float32 bit patterns
+// [first, first + count) and counts mismatches (out[0]) and inputs that took the exact fallback (out[1]).
+__global__ __launch_bounds__(256) void k_minh_selftest(int which, uint64_t first, uint64_t count, unsigned long long* out) {
+    __shared__ FastTables tb;
+    fast_tables_load(&tb);
+    unsigned long long bad = 0, slow = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const float v = __uint_as_float((uint32_t)(first + i));
+        float fast, exact;
+        bool fell_back;
+        if (which == 0) {
+            fast = go_log10_f32(v, &tb); exact = (float)go_log10((double)v);
+            const uint32_t xb = __float_as_uint(v);
+            fell_back = !(xb - 0x00800000u < 0x7f000000u);
+        } else {
+            fast = go_pow10_f32(v, &tb); exact = (float)go_pow10((double)v);
+            const float ay = fabsf(v);
+            fell_back = !(ay < 37.5f && ay > 1e-6f && v != 1.0f && ay != 0.5f);
+        }
+        const uint32_t a = __float_as_uint(fast), b = __float_as_uint(exact);
+        const bool both_nan = (fast != fast) && (exact != exact);
+        if (a != b && !both_nan) ++bad;
+        if (fell_back) ++slow;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (slow) atomicAdd(&out[1], slow);
+}
+
 constexpr int kMinhBatch = 64;
 struct MinhCol {
     const float* src;
@@ -19,32 +47,36 @@ struct MinhArgs {
 };
 
 __global__ __launch_bounds__(256) void k_minh_process(MinhArgs a) {
+    __shared__ FastTables tb;
     const MinhCol c = a.col[blockIdx.y];
+    if (c.xform & kXfLog10) fast_tables_load(&tb);          // block-uniform
     const int64_t n4 = ((((uintptr_t)c.src | (uintptr_t)c.dst) & 15) == 0) ? c.n / 4 : 0;
     const int64_t step = (int64_t)gridDim.x * 256;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += step) {
         f32x4 v = ldg<f32x4>(c.src + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = xf_apply(v[e], c.xform, c.low, c.high, c.high_below);
+        for (int e = 0; e < 4; ++e) v[e] = xf_apply_fast(v[e], c.xform, c.low, c.high, c.high_below, &tb);
         stg<f32x4>(c.dst + 4 * q, v);
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n; i += step)
-        c.dst[i] = xf_apply(c.src[i], c.xform, c.low, c.high, c.high_below);
+        c.dst[i] = xf_apply_fast(c.src[i], c.xform, c.low, c.high, c.high_below, &tb);
 }
 
 // float32(math.Pow(10, float64(x))), in place
 __global__ __launch_bounds__(256) void k_minh_unlog(MinhArgs a) {
+    __shared__ FastTables tb;
+    fast_tables_load(&tb);
     const MinhCol c = a.col[blockIdx.y];
     const int64_t n4 = (((uintptr_t)c.dst & 15) == 0) ? c.n / 4 : 0;
     const int64_t step = (int64_t)gridDim.x * 256;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += step) {
         f32x4 v = ldg<f32x4>(c.dst + 4 * q);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)go_pow10((double)v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = go_pow10_f32(v[e], &tb);
         stg<f32x4>(c.dst + 4 * q, v);
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < c.n; i += step)
-        c.dst[i] = (float)go_pow10((double)c.dst[i]);
+        c.dst[i] = go_pow10_f32(c.dst[i], &tb);
 }
 
 void launch_minh_process(hipStream_t s, int cus, const MinhArgs& a, int ncols, int64_t max_n) {
@@ -60,4 +92,7 @@ void launch_minh_unlog(hipStream_t s, int cus, const MinhArgs& a, int ncols, int
     if (gx > cap) gx = cap;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_minh_unlog, dim3((unsigned)gx, (unsigned)ncols), dim3(256), 0, s, a);
+}
+void launch_minh_selftest(hipStream_t s, int which, uint64_t first, uint64_t count, unsigned long long* out) {
+    hipLaunchKernelGGL(k_minh_selftest, dim3(4096), dim3(256), 0, s, which, first, count, out);
 }

@@ -35,17 +35,39 @@ def test_header_symbols_all_exported(mnw):
 
 def test_abi_version_and_strerror(mnw):
     L = mnw.lib()
-    assert L.mnw_abi_version() == 1
+    assert L.mnw_abi_version() == 2
     assert b"ok" == L.mnw_strerror(0)
     assert b"fallback" in L.mnw_strerror(-3)
 
 
 def test_struct_layouts_match_header(mnw):
     from minnow_amd import _lib
-    assert C.sizeof(_lib.EncJobC) == 56
-    assert C.sizeof(_lib.DecJobC) == 88
+    assert C.sizeof(_lib.EncJobC) == 64
+    assert C.sizeof(_lib.DecJobC) == 96
     assert C.sizeof(_lib.BlockMetaC) == 32
     assert C.sizeof(_lib.KernelTimeC) == 16
+    # and against the header itself, as a C compiler lays the structs out
+    import subprocess
+    import tempfile
+    prog = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "minnow_hip.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mnw_enc_job), offsetof(mnw_enc_job, xform), sizeof(mnw_dec_job),
+           offsetof(mnw_dec_job, xform), sizeof(mnw_block_meta), sizeof(mnw_kernel_time), sizeof(mnw_minh_col),
+           offsetof(mnw_minh_col, log));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "l.c"), os.path.join(td, "l")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(_lib.EncJobC), _lib.EncJobC.xform.offset, C.sizeof(_lib.DecJobC), _lib.DecJobC.xform.offset,
+            C.sizeof(_lib.BlockMetaC), C.sizeof(_lib.KernelTimeC), C.sizeof(_lib.MinhColC), _lib.MinhColC.log.offset]
+    assert got == want
 
 
 def test_host_scalars_match_oracle(mnw, oracle):

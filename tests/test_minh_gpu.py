@@ -104,3 +104,77 @@ def test_log_column_of_reference_test(mnw, oracle, torch_mod):
                 assert np.all(np.abs(np.log10(got.astype(np.float64)) - np.log10(x.astype(np.float64))) <= dx * 1.001 + 1e-6)
             else:     # float32sEq with eps = dx; x == high is clamped to just below it
                 assert np.all(np.abs(got.astype(np.float64) - np.minimum(x, np.nextafter(np.float32(high), np.float32(0)))) <= dx * 1.001 + 1e-4)
+
+
+@pytest.mark.parametrize("which,name", [(0, "log10"), (1, "pow10")])
+def test_fast_paths_equal_exact_for_every_float32(mnw, which, name):
+    """The kernels compute float32(Log10(float64(x))) / float32(Pow(10, float64(y))) through a table + polynomial
+    with a rounding-ambiguity check and fall back to the exact restatement otherwise.  Exhaustive: all 2^32 float32
+    bit patterns, zero mismatches allowed."""
+    import ctypes as C
+    from minnow_amd import _lib
+    L = _lib.lib()
+    with mnw.Context(0) as c:
+        out = (C.c_uint64 * 2)()
+        bad = slow = 0
+        for part in range(4):
+            assert L.mnw_minh_selftest(c.handle, which, part << 30, 1 << 30, out) == 0
+            bad += out[0]; slow += out[1]
+        assert bad == 0, "%s: %d float32 inputs where the fast path differs from the exact one" % (name, bad)
+        # the fast path's domain: positive normal x (log10: half of all patterns), |y| in (1e-6, 37.5) (pow10: a tenth of all patterns, all that 10^y maps into float32's range)
+        assert slow < (1 << 32) * (0.51 if which == 0 else 0.92)
+
+
+@pytest.mark.parametrize("mode", ["single_read", "two_pass", "fused"])
+def test_transform_inside_the_codec_jobs(mnw, oracle, torch_mod, mode):
+    """mnw_enc_job.xform / mnw_dec_job.xform: processFloatGroup applied while the block is encoded (at load time in the
+    single-read kernel, through a staging copy in the other structures and in the exact path) and 10^x while it is
+    decoded.  Against the oracle's processFloatGroup -> floatGroup.writeData and readData -> 10^x."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(61)
+    cols = []
+    for n in (1, 4097, 8192, 100001, 2**20 + 3):
+        cols.append((mnw.XF_LOG10 | mnw.XF_CLAMP, 8.0, 16.0, 0.01, (10 ** rng.uniform(7.5, 16.5, n)).astype(np.float32)))
+        cols.append((mnw.XF_CLAMP, 100.0, 200.0, 1.0, rng.uniform(90, 210, n).astype(np.float32)))
+    zero = (10 ** rng.uniform(9, 12, 30000)).astype(np.float32); zero[17] = 0.0          # log10(0) = -Inf -> Low
+    cols.append((mnw.XF_LOG10 | mnw.XF_CLAMP, 8.0, 16.0, 0.01, zero))
+    neg = (10 ** rng.uniform(9, 12, 30000)).astype(np.float32); neg[5] = -3.0            # log10(<0) = NaN -> exact path
+    cols.append((mnw.XF_LOG10 | mnw.XF_CLAMP, 8.0, 16.0, 0.01, neg))
+    cols.append((0, 0.0, 250.0, 0.001, np.mod(125 + 20 * rng.standard_normal(50000), 250).astype(np.float32)))   # plain
+    with mnw.Context(0) as c:
+        if mode == "two_pass":
+            c.set_option("single_read", 0)
+        elif mode == "fused":
+            c.set_option("fused", 1)
+        ts = [torch.from_numpy(x).to(dev) for *_, x in cols]
+        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for *_, x in cols]
+        ys = [torch.empty_like(t) for t in ts]
+        pix = [mnw.float_group_pixels(lo, hi, dx) for _, lo, hi, dx, _ in cols]
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, lo, hi, p, 1, xform=xf)
+                for (xf, lo, hi, dx, x), t, o, p in zip(cols, ts, outs, pix)]
+        torch.cuda.synchronize()
+        c.timing_enable(True)
+        for rep in range(2):
+            metas = c.encode_blocks(jobs)
+        torch.cuda.synchronize()
+        ran = {k for k, v in c.timing_get().items() if v["launches"]}
+        assert {"single_read": "k_encode_reg_f32", "two_pass": "k_pack_f32", "fused": "k_encode_f32"}[mode] in ran
+        assert ("k_minh_process" in ran)                       # the staging copy (always for the exact-path block)
+        djobs = []
+        for b, ((xf, lo, hi, dx, x), m, o, y, p) in enumerate(zip(cols, metas, outs, ys, pix)):
+            pb = oracle.process_float_group(x, xf & mnw.XF_LOG10, lo, hi) if xf else x
+            omin, obits, odata = oracle.float_encode(pb, lo, hi, p, True, literal=False)
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), b
+            assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), b
+            djobs.append(mnw.DecJob(o.data_ptr(), y.data_ptr(), x.size, m.nbytes, m.min, m.bits, mnw.FLOAT_GROUP, lo, hi, p, 1,
+                                    seed=3, block=b, xform=xf & mnw.XF_LOG10))
+        c.decode_blocks(djobs)
+        torch.cuda.synchronize()
+        for b, ((xf, lo, hi, dx, x), m, o, y, p) in enumerate(zip(cols, metas, outs, ys, pix)):
+            odata = o[: m.nbytes].cpu().numpy()
+            ref = oracle.float_decode(odata, m.min, m.bits, lo, hi, p, True, x.size, u=oracle.dither(3, b, x.size), literal=False)
+            if xf & mnw.XF_LOG10:
+                ref = oracle.unlog(ref)
+            got = y.cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(ref)) or np.array_equal(got, ref, equal_nan=True), b

@@ -20,6 +20,9 @@ p.add_argument("--rows", type=int, default=10**8)
 p.add_argument("--block", type=int, default=2**20)
 p.add_argument("--reps", type=int, default=3)
 p.add_argument("--blocks-per-call", type=int, default=1, help="row blocks handed to the library per call")
+p.add_argument("--in-jobs", action="store_true", help="with --minh: pass the transforms as job flags (mnw_enc_job.xform) instead of separate calls")
+p.add_argument("--minh", action="store_true", help="include minh's processFloatGroup before the encode (the 18 log columns start as raw\n"
+               "values, log10 + clamp on the GPU) and 10^x after the decode")
 a = p.parse_args()
 dev = torch.device("cuda:0")
 R, B = a.rows, a.block
@@ -31,7 +34,8 @@ for c in range(3):
 for c in range(3):
     cols.append(("f", torch.clamp(300 * torch.randn(R, device=dev, generator=g), -4999, 4999).contiguous(), (-5000.0, 5000.0, 1.0)))
 for c in range(18):
-    cols.append(("f", torch.clamp(10 + 0.2 * c + 0.8 * torch.randn(R, device=dev, generator=g), 8.001, 15.99).contiguous(), (8.0, 16.0, 0.01)))
+    lg = torch.clamp(10 + 0.2 * c + 0.8 * torch.randn(R, device=dev, generator=g), 8.001, 15.99).contiguous()
+    cols.append(("L" if a.minh else "f", (10.0 ** lg.double()).float().contiguous() if a.minh else lg, (8.0, 16.0, 0.01)))
 cols.append(("i", (5 * 10**9 + torch.arange(R, device=dev, dtype=torch.int64)), None))
 cols.append(("i", torch.poisson(torch.full((R,), 40.0, device=dev), generator=g).to(torch.int64), None))
 cols.append(("i", torch.randint(-1, 2**20, (R,), device=dev, dtype=torch.int64, generator=g), None))
@@ -40,6 +44,10 @@ nblk = (R + B - 1) // B
 ctx = mnw.Context(0)
 in_bytes = sum(t.numel() * t.element_size() for _, t, _ in cols)
 outs, decs, enc_batches, dec_protos = [], [], [], []
+# minh.Writer.Block's buffer (minh.buf): the processed copy of every FloatGroup column, encoded from there
+bufs = [torch.empty_like(t) if (a.minh and not a.in_jobs and kind != "i") else None for kind, t, _ in cols]
+proc_cols = [(t.data_ptr(), bufs[ci].data_ptr(), R, lim[0], lim[1], 1 if kind == "L" else 0) for ci, (kind, t, lim) in enumerate(cols) if bufs[ci] is not None]
+unlog_cols = [(ci, kind) for ci, (kind, t, lim) in enumerate(cols) if kind == "L"]
 for kind, t, lim in cols:
     esz = t.element_size()
     slot = (esz * B + 15) // 16 * 16
@@ -51,11 +59,13 @@ for b in range(nblk):
     for ci, (kind, t, lim) in enumerate(cols):
         o, slot = outs[ci]
         esz = t.element_size()
-        if kind == "f":
+        if kind != "i":
             low, high, dx = lim
             pix = mnw.float_group_pixels(low, high, dx)
-            ej.append(mnw.EncJob(t.data_ptr() + esz * b * B, o.data_ptr() + b * slot, n, slot, mnw.FLOAT_GROUP, low, high, pix, 1))
-            dj.append(mnw.DecJob(o.data_ptr() + b * slot, decs[ci].data_ptr() + esz * b * B, n, 0, 0, 0, mnw.FLOAT_GROUP, low, high, pix, 1, seed=1, block=b * len(cols) + ci))
+            src = bufs[ci] if bufs[ci] is not None else t
+            xf = ((mnw.XF_LOG10 if kind == "L" else 0) | mnw.XF_CLAMP) if (a.minh and a.in_jobs) else 0
+            ej.append(mnw.EncJob(src.data_ptr() + esz * b * B, o.data_ptr() + b * slot, n, slot, mnw.FLOAT_GROUP, low, high, pix, 1, xform=xf))
+            dj.append(mnw.DecJob(o.data_ptr() + b * slot, decs[ci].data_ptr() + esz * b * B, n, 0, 0, 0, mnw.FLOAT_GROUP, low, high, pix, 1, seed=1, block=b * len(cols) + ci, xform=xf & mnw.XF_LOG10))
         else:
             ej.append(mnw.EncJob(t.data_ptr() + esz * b * B, o.data_ptr() + b * slot, n, slot, mnw.INT_GROUP))
             dj.append(mnw.DecJob(o.data_ptr() + b * slot, decs[ci].data_ptr() + esz * b * B, n, 0, 0, 0, mnw.INT_GROUP))
@@ -68,6 +78,8 @@ torch.cuda.synchronize()
 
 def encode_all():
     metas = []
+    if a.minh and not a.in_jobs:
+        ctx.minh_process(proc_cols)
     for eb in enc_batches:
         metas.append(ctx.encode_blocks(eb, raw=True))
     return metas
@@ -77,6 +89,8 @@ def decode_all(metas):
     for db, m in zip(dec_protos, metas):
         ctx.dec_batch_update(db, m)
         ctx.decode_blocks(db)
+    if a.minh and not a.in_jobs:
+        ctx.minh_unlog([(decs[ci].data_ptr(), R) for ci, _ in unlog_cols])
 
 
 for _ in range(4):
@@ -96,6 +110,9 @@ packed = sum(m.nbytes for mb in metas for m in ctx.metas_of(mb))
 for ci, (kind, t, lim) in enumerate(cols):
     if kind == "i":
         assert torch.equal(decs[ci], t), ci
+    elif kind == "L":
+        d = (torch.log10(decs[ci].double()) - torch.log10(t.double())).abs()
+        assert float(d.max()) <= lim[2] * 1.01 + 1e-3, (ci, float(d.max()))
     else:
         d = (decs[ci].double() - t.double()).abs()
         if lim[0] == 0.0:
@@ -105,7 +122,7 @@ ctx.timing_enable(True); ctx.timing_reset()
 metas = encode_all(); decode_all(metas); torch.cuda.synchronize()
 kt = {k: v for k, v in ctx.timing_get().items() if v["launches"]}
 print(json.dumps({
-    "rows": R, "block": B, "blocks_per_call": a.blocks_per_call, "columns": len(cols), "input_GB": in_bytes / 1e9, "packed_GB": packed / 1e9,
+    "rows": R, "block": B, "minh_transforms": ("in jobs" if a.in_jobs else "separate calls") if a.minh else False, "blocks_per_call": a.blocks_per_call, "columns": len(cols), "input_GB": in_bytes / 1e9, "packed_GB": packed / 1e9,
     "encode_ms": t_enc * 1e3, "decode_ms": t_dec * 1e3,
     "encode_GBps_input": in_bytes / t_enc / 1e9, "decode_GBps_output": in_bytes / t_dec / 1e9,
     "encode_frac_of_8TBps": (in_bytes + packed) / t_enc / 8e12, "decode_frac_of_8TBps": (in_bytes + packed) / t_dec / 8e12,

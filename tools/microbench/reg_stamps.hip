@@ -42,9 +42,9 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(dj, hj.data(), sizeof(DevJob) * nj, hipMemcpyHostToDevice)); CHK(hipMemset(recs, 0, sizeof(ItemRec) * items)); CHK(hipMemset(ab, 0, 128));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     uint32_t gen = 1;
-    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1); }
+    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1, 0); }
     CHK(hipDeviceSynchronize()); CHK(hipMemset(sb, 0, 8 * 8 * 4096));
-    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1, 0); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
     float ms; CHK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> h(8 * grid); CHK(hipMemcpy(h.data(), sb, 8 * 8 * grid, hipMemcpyDeviceToHost));
     Meta m0; CHK(hipMemcpy(&m0, dm, sizeof m0, hipMemcpyDeviceToHost)); uint32_t abv; CHK(hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost));
