@@ -96,10 +96,22 @@ def run(budget=60.0, seed=12345):
                 if pixels <= 0:
                     continue
                 x = rand_float_block(n, low, high)
+                xf = 0
+                r = rng.random()
+                if r < 0.15:                          # minh column: clamp only, values partly outside [low, high)
+                    xf = mnw.XF_CLAMP
+                    x = (low + (high - low) * rng.uniform(-0.1, 1.1, n)).astype(np.float32)
+                elif r < 0.3:                         # minh logarithmic column
+                    xf = mnw.XF_CLAMP | mnw.XF_LOG10
+                    low, high, dx = 8.0, 16.0, 0.01
+                    pixels = mnw.float_group_pixels(low, high, dx)
+                    x = (10 ** rng.uniform(7.8, 16.2, n)).astype(np.float32)
+                    if rng.random() < 0.2:
+                        x[rng.integers(0, n)] = [0.0, -1.0, np.inf, 1.0][rng.integers(0, 4)]
                 t = torch.from_numpy(x).to(dev)
                 o = torch.zeros(8 * n + 16, dtype=torch.uint8, device=dev)
-                jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), n, o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1))
-                specs.append(("f", x, (low, high, pixels)))
+                jobs.append(mnw.EncJob(t.data_ptr(), o.data_ptr(), n, o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1, xform=xf))
+                specs.append(("f", x, (low, high, pixels, xf)))
             else:
                 x = rand_int_block(n)
                 t = torch.from_numpy(x).to(dev)
@@ -116,9 +128,10 @@ def run(budget=60.0, seed=12345):
         for (kind, x, par), m, (t, o) in zip(specs, metas, keep):
             n = x.size
             if kind == "f":
-                low, high, pixels = par
+                low, high, pixels, xf = par
                 try:
-                    omin, obits, odata = orc.float_encode(x, low, high, pixels, True, literal=False)
+                    xp = orc.process_float_group(x, xf & mnw.XF_LOG10, low, high) if xf else x
+                    omin, obits, odata = orc.float_encode(xp, low, high, pixels, True, literal=False)
                 except Exception as e:      # the oracle reports what the reference would panic on
                     assert m.status != 0, ("oracle refused but GPU accepted", e)
                     continue
@@ -139,7 +152,7 @@ def run(budget=60.0, seed=12345):
             if kind == "f":
                 y = torch.empty(n, dtype=torch.float32, device=dev)
                 djobs.append(mnw.DecJob(s2.data_ptr() + off, y.data_ptr(), n, m.nbytes, m.min, m.bits, mnw.FLOAT_GROUP, par[0], par[1], par[2], 1,
-                                        seed=7, block=blocks))
+                                        seed=7, block=blocks, xform=par[3] & mnw.XF_LOG10))
             else:
                 y = torch.empty(n, dtype=torch.int64, device=dev)
                 djobs.append(mnw.DecJob(s2.data_ptr() + off, y.data_ptr(), n, m.nbytes, m.min, m.bits, mnw.INT_GROUP))
@@ -153,6 +166,8 @@ def run(budget=60.0, seed=12345):
             n = x.size
             if kind == "f":
                 ref = orc.float_decode(odata, m.min, m.bits, par[0], par[1], par[2], True, n, u=orc.dither(7, blk, n), literal=False)
+                if par[3] & mnw.XF_LOG10:
+                    ref = orc.unlog(ref)
                 got = y.cpu().numpy()
                 ok = np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref, dtype=np.float32).view(np.uint32)) or np.array_equal(got, ref, equal_nan=True)
             else:
