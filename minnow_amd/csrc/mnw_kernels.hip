@@ -512,7 +512,6 @@ constexpr int kGroup = 32;                         // elements packed by one lan
 constexpr int kStride32 = kGroup + 4;              // dwords between groups of 32-bit values
 constexpr int kStride64 = 2 * kGroup + 4;          // dwords between groups of 64-bit values
 constexpr int kLds32 = kThreads * kStride32 * 4;   // 36,864 B
-constexpr int kLds64 = kThreads * kStride64 * 4;   // 69,632 B
 static_assert(kTile == kThreads * kGroup, "one lane packs one group of the tile");
 
 // position of element e of the tile in the padded 32-bit stage (dword index)
@@ -948,7 +947,7 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
 constexpr int kThreadsR = 256;
 constexpr int kItem = kThreadsR * kGroup;           // 8,192 elements: one lane packs one group of the item
 constexpr int kBufR = kThreadsR * kStride32;        // dwords of one parked item (padded stage layout)
-constexpr int kLdsR = kBufR * 4;                    // 36,864 B: four workgroups per CU
+static_assert(kBufR * 4 == 36864, "36 KB of LDS for the parked item: four workgroups per CU");
 constexpr int kMaxSweep = 512;                      // items per block the sweep handles (2^22 elements)
 __device__ __forceinline__ int64_t items_of(int64_t n) { return (n + kItem - 1) / kItem; }
 
