@@ -121,8 +121,10 @@ def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup,
                                         0, 0, mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1, seed=1, block=k)
                              for k in range(nblk)])
 
+    meta_buf = [None]
+
     def step():
-        meta = ctx.encode_blocks(enc_arr, stream=stream, raw=True)   # returns with (min, bits, nbytes) per block
+        meta = meta_buf[0] = ctx.encode_blocks(enc_arr, stream=stream, raw=True, meta_out=meta_buf[0])   # (min, bits, nbytes) per block
         ctx.dec_batch_update(dec_arr, meta)
         ctx.decode_blocks(dec_arr, stream=stream)
         return meta

@@ -134,12 +134,13 @@ class Context:
     def _count(jobs):
         return jobs._n if isinstance(jobs, C.Array) else len(jobs)
 
-    def encode_blocks(self, jobs, stream=None, check=True, raw=False):
+    def encode_blocks(self, jobs, stream=None, check=True, raw=False, meta_out=None):
         """raw=True returns the C array of mnw_block_meta itself (see `metas_of`, `dec_batch_update`): a
-        caller that runs many small blocks per call avoids one Python object per block that way."""
+        caller that runs many small blocks per call avoids one Python object per block that way.  meta_out: a raw
+        array returned by an earlier call, filled again instead of allocating a new one."""
         arr = self._enc_array(jobs)
         n = self._count(arr)
-        meta = (BlockMetaC * max(n, 1))()
+        meta = meta_out if meta_out is not None else (BlockMetaC * max(n, 1))()
         meta._n = n
         rc = self._L.mnw_encode_blocks(self._h, stream, arr, n, meta)
         if check:
@@ -156,8 +157,12 @@ class Context:
         what a reader does with intGroup.mins/bits and the block index (group.go:257-263), vectorised."""
         import numpy as np
         n = arr._n
-        d = np.frombuffer(arr, dtype=_DEC_DTYPE, count=n)
-        m = np.frombuffer(meta, dtype=_META_DTYPE, count=n)
+        d = getattr(arr, "_np", None)
+        if d is None:
+            d = arr._np = np.frombuffer(arr, dtype=_DEC_DTYPE, count=n)
+        m = getattr(meta, "_np", None)
+        if m is None:
+            m = meta._np = np.frombuffer(meta, dtype=_META_DTYPE, count=n)
         d["min"] = m["min"]
         d["bits"] = m["bits"]
         d["src_len"] = m["nbytes"]
