@@ -223,6 +223,21 @@ int mnw_minh_unlog(mnw_ctx *ctx, mnw_stream_t stream, const mnw_minh_col *cols, 
  * out[1] = inputs outside the fast path's domain.  Synchronous.  The GPU tests run it over all 2^32 patterns. */
 int mnw_minh_selftest(mnw_ctx *ctx, int which, uint64_t first, uint64_t count, uint64_t out[2]);
 
+/* ---- text catalogue ingest (go/text) ---------------------------------------------------------------
+ * text.Reader.Block after the file read (go/text/text.go:176-197, go/text/parse.go): the block of text is split at
+ * '\n', comments ("data # comment") are cut, lines holding nothing but separators are dropped, every remaining line
+ * is broken into fields at runs of `sep`, and the requested fields are converted: int columns with strconv.Atoi,
+ * float columns with float32(strconv.ParseFloat(s, 64)).  text is a HOST buffer (the reader's rd.buf); the outputs
+ * are DEVICE arrays of `capacity_rows` elements each, ready to be handed to mnw_encode_blocks: float_out[k] receives
+ * field float_cols[k], int_out[k] field int_cols[k] (0-based field numbers, at most 48 of each, fields < 256).
+ * *n_rows = lines kept.  Every kept line must have as many fields as the first kept line has whitespace-separated
+ * words (parse.go:96-103); a line that does not, or a field that Atoi / ParseFloat would reject, gives MNW_E_DOMAIN
+ * (the reference panics) with the line in mnw_last_error.  Synchronous. */
+int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t sep, uint8_t comment,
+                   const int32_t *float_cols, int n_float, float *const *float_out,
+                   const int32_t *int_cols, int n_int, int64_t *const *int_out,
+                   int64_t capacity_rows, int64_t *n_rows);
+
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */
 int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
@@ -250,7 +265,9 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_UNPACK_VEC3 13  /* minp vectors without staging: the three streams of a sub-cell into the grid */
 #define MNW_K_MINH_PROCESS 14 /* minh processFloatGroup over device columns */
 #define MNW_K_MINH_UNLOG  15  /* minh reader: 10^x */
-#define MNW_K_COUNT       16
+#define MNW_K_TEXT_LINES  16  /* text ingest: newline count + line starts + kept-line flags */
+#define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers, one thread per line */
+#define MNW_K_COUNT       18
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;

@@ -10,7 +10,7 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 16
+K_COUNT = 18
 
 
 class MnwError(RuntimeError):
@@ -89,6 +89,8 @@ SIGNATURES = {
     "mnw_minh_process": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
     "mnw_minh_unlog": (_int, [_p, _p, C.POINTER(MinhColC), _int]),
     "mnw_minh_selftest": (_int, [_p, _int, _u64, _u64, C.POINTER(_u64)]),
+    "mnw_text_parse": (_int, [_p, _p, _i64, C.c_uint8, C.c_uint8, C.POINTER(C.c_int32), _int, C.POINTER(_p),
+                              C.POINTER(C.c_int32), _int, C.POINTER(_p), _i64, C.POINTER(_i64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),

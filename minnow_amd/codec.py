@@ -234,6 +234,19 @@ class Context:
         arr = (MinhColC * max(len(cols), 1))(*[MinhColC(None, d, n, 0.0, 0.0, 1, 0) for d, n in cols])
         self._check(self._L.mnw_minh_unlog(self._h, stream, arr, len(cols)))
 
+    # -- text catalogue ingest (go/text) ------------------------------------------------------------
+    def text_parse(self, data, sep, comment, float_cols, float_out_ptrs, int_cols, int_out_ptrs, capacity_rows):
+        """data: bytes-like host text; *_out_ptrs: device pointers of capacity_rows elements each -> rows kept"""
+        buf = data if isinstance(data, bytes) else bytes(data)          # passed as a pointer to the bytes object's buffer: no copy
+        fc = (C.c_int32 * max(len(float_cols), 1))(*float_cols)
+        ic = (C.c_int32 * max(len(int_cols), 1))(*int_cols)
+        fo = (C.c_void_p * max(len(float_out_ptrs), 1))(*float_out_ptrs)
+        io = (C.c_void_p * max(len(int_out_ptrs), 1))(*int_out_ptrs)
+        n = C.c_int64(0)
+        self._check(self._L.mnw_text_parse(self._h, buf, len(data), sep, comment, fc, len(float_cols), fo, ic, len(int_cols), io,
+                                           capacity_rows, C.byref(n)))
+        return n.value
+
     def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
         self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))
 

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <errno.h>
 
 #include <string>
 #include <vector>
@@ -41,6 +43,15 @@ struct MinhArgs { MinhCol col[kMinhBatch]; };
 void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_selftest(hipStream_t, int, uint64_t, uint64_t, unsigned long long*);
+constexpr int kTextTile = 16384, kTextMaxCols = 256, kTextMaxOut = 48;
+struct TextCols { int16_t slot[kTextMaxCols]; float* fout[kTextMaxOut]; int64_t* iout[kTextMaxOut]; int32_t fields_expected; int32_t max_field; };
+struct TextSlow { int64_t row; int64_t offset; int32_t len; int32_t slot; };
+struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned int pad; };
+void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint32_t*);
+void launch_text_lines(hipStream_t, const uint8_t*, int64_t, const int64_t*, int64_t*);
+void launch_text_valid(hipStream_t, const uint8_t*, const int64_t*, int64_t, uint8_t, uint8_t, uint8_t*, uint32_t*);
+void launch_text_parse(hipStream_t, const uint8_t*, const int64_t*, int64_t, uint8_t, uint8_t, const uint8_t*, const int64_t*, const TextCols&,
+                       TextSlow*, unsigned, TextState*);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -123,6 +134,11 @@ struct mnw_ctx {
     // the processed copy of the block, like minh.buf (go/minh/minh.go:128-133)
     size_t cap_xf = 0;
     float* d_xf = nullptr;
+
+    // text ingest scratch (grow-only): the text, line starts, kept-line flags, per-tile counts and bases, slow list
+    size_t cap_text = 0, cap_lines = 0, cap_valid = 0, cap_tile = 0, cap_tbase = 0;
+    void* d_text = nullptr; void* d_lines = nullptr; void* d_valid = nullptr; void* d_tile = nullptr; void* d_tbase = nullptr;
+    void* d_tslow = nullptr; void* d_tstate = nullptr;
 
     // exact path scratch
     size_t cap_q = 0;
@@ -684,6 +700,8 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_UNPACK_VEC3: return "k_unpack_vec3";
         case MNW_K_MINH_PROCESS: return "k_minh_process";
         case MNW_K_MINH_UNLOG: return "k_minh_unlog";
+        case MNW_K_TEXT_LINES: return "k_text_lines";
+        case MNW_K_TEXT_PARSE: return "k_text_parse";
         default: return "";
     }
 }
@@ -721,6 +739,7 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_recs) hipFree(c->d_recs);
     if (c->d_soa) hipFree(c->d_soa);
     if (c->d_xf) hipFree(c->d_xf);
+    for (void* q : {c->d_text, c->d_lines, c->d_valid, c->d_tile, c->d_tbase, c->d_tslow, c->d_tstate}) if (q) hipFree(q);
     if (c->d_bkeys) hipFree(c->d_bkeys);
     if (c->h_bkeys) hipHostFree(c->h_bkeys);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1279,6 +1298,166 @@ int mnw_minh_selftest(mnw_ctx* c, int which, uint64_t first, uint64_t count, uin
 
 int mnw_minh_process(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, false); }
 int mnw_minh_unlog(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, int ncols) { return minh_launch(c, stream, cols, ncols, true); }
+
+// ---- text catalogue ingest (go/text/text.go:176-197, go/text/parse.go) --------------------------------
+namespace {
+constexpr unsigned kTextSlowCap = 1u << 20;
+
+bool go_is_space(uint8_t ch) {      // unicode.IsSpace for the Latin-1 range, as bytes.Fields sees single bytes
+    return ch == ' ' || (ch >= '\t' && ch <= '\r') || ch == 0x85 || ch == 0xA0;
+}
+}  // namespace
+
+int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment,
+                   const int32_t* float_cols, int n_float, float* const* float_out,
+                   const int32_t* int_cols, int n_int, int64_t* const* int_out, int64_t capacity_rows, int64_t* n_rows) {
+    if (!c || !n_rows || nbytes < 0 || n_float < 0 || n_int < 0 || (nbytes > 0 && !text)) return fail(c, MNW_E_ARG, "text: bad arguments");
+    if (n_float > mnw::kTextMaxOut || n_int > mnw::kTextMaxOut) return fail(c, MNW_E_ARG, "text: at most 48 columns of each type per call");
+    if ((n_float > 0 && (!float_cols || !float_out)) || (n_int > 0 && (!int_cols || !int_out))) return fail(c, MNW_E_ARG, "text: null column arrays");
+    if (sep == '\n' || comment == '\n') return fail(c, MNW_E_ARG, "text: the newline cannot be the separator or the comment character");
+    *n_rows = 0;
+    if (nbytes == 0) return MNW_OK;
+    mnw::TextCols cols;
+    memset(&cols, 0, sizeof cols);
+    for (int k = 0; k < mnw::kTextMaxCols; ++k) cols.slot[k] = -1;
+    cols.max_field = -1;
+    for (int k = 0; k < n_float + n_int; ++k) {
+        const bool isf = k < n_float;
+        const int32_t f = isf ? float_cols[k] : int_cols[k - n_float];
+        if (f < 0 || f >= mnw::kTextMaxCols) return fail(c, MNW_E_ARG, "text: field numbers must be in 0..255");
+        if (cols.slot[f] != -1) return fail(c, MNW_E_ARG, "text: a field may be requested once");
+        if (isf) { if (!float_out[k]) return fail(c, MNW_E_ARG, "text: null output"); cols.slot[f] = (int16_t)k; cols.fout[k] = float_out[k]; }
+        else { if (!int_out[k - n_float]) return fail(c, MNW_E_ARG, "text: null output"); cols.slot[f] = (int16_t)(0x4000 + k - n_float); cols.iout[k - n_float] = int_out[k - n_float]; }
+        if (f > cols.max_field) cols.max_field = f;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
+    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 4 + 16);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_tbase, &c->cap_tbase, (size_t)tiles * 8 + 16);
+    if (rc) return rc;
+    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
+    if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
+    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    const uint8_t* dtext = (const uint8_t*)c->d_text;
+    // ---- lines --------------------------------------------------------------------------------------------
+    std::vector<uint32_t> tcount((size_t)tiles);
+    std::vector<int64_t> tbase((size_t)tiles);
+    int64_t nl = 0;
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
+        mnw::launch_text_count(s, dtext, nbytes, (uint32_t*)c->d_tile);
+    }
+    HIPCHK(c, hipMemcpyAsync(tcount.data(), c->d_tile, (size_t)tiles * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int64_t t = 0; t < tiles; ++t) { tbase[(size_t)t] = nl; nl += tcount[(size_t)t]; }
+    const int64_t nlines = nl + 1;                                  // split(): n + 1 tokens, parse.go:22
+    rc = ensure_dev(c, &c->d_lines, &c->cap_lines, (size_t)(nlines + 1) * 8);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_valid, &c->cap_valid, (size_t)nlines + 16);
+    if (rc) return rc;
+    int64_t* dlines = (int64_t*)c->d_lines;
+    const int64_t first = 0, last = nbytes + 1;
+    HIPCHK(c, hipMemcpyAsync(dlines, &first, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dlines + nlines, &last, 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_tbase, tbase.data(), (size_t)tiles * 8, hipMemcpyHostToDevice, s));
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
+        mnw::launch_text_lines(s, dtext, nbytes, (const int64_t*)c->d_tbase, dlines);
+    }
+    // ---- kept lines -----------------------------------------------------------------------------------------
+    const int64_t vtiles = (nlines + 255) / 256;
+    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)vtiles * 4 + 16);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_tbase, &c->cap_tbase, (size_t)vtiles * 8 + 16);
+    if (rc) return rc;
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
+        mnw::launch_text_valid(s, dtext, dlines, nlines, sep, comment, (uint8_t*)c->d_valid, (uint32_t*)c->d_tile);
+    }
+    tcount.resize((size_t)vtiles); tbase.resize((size_t)vtiles);
+    HIPCHK(c, hipMemcpyAsync(tcount.data(), c->d_tile, (size_t)vtiles * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int64_t rows = 0;
+    for (int64_t t = 0; t < vtiles; ++t) { tbase[(size_t)t] = rows; rows += tcount[(size_t)t]; }
+    *n_rows = rows;
+    if (rows == 0) return MNW_OK;
+    if (rows > capacity_rows) return fail(c, MNW_E_CAPACITY, "text: more lines than capacity_rows");
+    // bufLen = len(bytes.Fields(lines[0])) (parse.go:96): words of the first kept line, split at white space
+    {
+        int64_t p = 0;
+        int words = -1;
+        while (p <= nbytes && words < 0) {
+            int64_t e = p;
+            while (e < nbytes && text[e] != '\n') ++e;
+            int64_t ce = p;
+            while (ce < e && text[ce] != comment) ++ce;
+            bool keep = false;
+            for (int64_t q = p; q < ce; ++q) if (text[q] != sep) { keep = true; break; }
+            if (keep) {
+                words = 0;
+                bool in = false;
+                for (int64_t q = p; q < ce; ++q) { const bool sp = go_is_space(text[q]); if (!sp && !in) ++words; in = !sp; }
+            }
+            p = e + 1;
+        }
+        cols.fields_expected = words;
+        if (cols.max_field >= words) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "Data has %d columns, but column %d was requested.", words, cols.max_field);    // parse.go:98-103
+            return fail(c, MNW_E_DOMAIN, buf);
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_tbase, tbase.data(), (size_t)vtiles * 8, hipMemcpyHostToDevice, s));
+    mnw::TextState st0 = {~0ull, 0u, 0u};
+    HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
+        mnw::launch_text_parse(s, dtext, dlines, nlines, sep, comment, (const uint8_t*)c->d_valid, (const int64_t*)c->d_tbase, cols,
+                               (mnw::TextSlow*)c->d_tslow, kTextSlowCap, (mnw::TextState*)c->d_tstate);
+    }
+    HIPCHK(c, hipGetLastError());
+    mnw::TextState st;
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_tstate, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (st.err_line != ~0ull) {
+        char buf[200];
+        const long long line = (long long)(st.err_line >> 8);
+        const int code = (int)(st.err_line & 0xff);
+        if (code == 1) snprintf(buf, sizeof buf, "Data on line %lld does not have %d columns.", line, cols.fields_expected);   // parse.go:114-118
+        else snprintf(buf, sizeof buf, "line %lld: strconv.%s: invalid syntax or value out of range", line, code == 2 ? "Atoi" : "ParseFloat");
+        return fail(c, MNW_E_DOMAIN, buf);
+    }
+    // ---- literals the device left alone: strtod is correctly rounded like strconv.ParseFloat ---------------------
+    if (st.n_slow > kTextSlowCap) return fail(c, MNW_E_NOMEM, "text: too many literals outside the device's fast path");
+    if (st.n_slow > 0) {
+        std::vector<mnw::TextSlow> sl(st.n_slow);
+        HIPCHK(c, hipMemcpy(sl.data(), c->d_tslow, sizeof(mnw::TextSlow) * st.n_slow, hipMemcpyDeviceToHost));
+        for (const mnw::TextSlow& w : sl) {
+            std::string tok((const char*)text + w.offset, (size_t)w.len);
+            // Go: "inf", "+Inf", "infinity", "nan" in any case; strtod agrees, and also on hex floats with a 'p' exponent
+            char* endp = nullptr;
+            errno = 0;
+            const double v = strtod(tok.c_str(), &endp);
+            if (endp != tok.c_str() + tok.size() || tok.find('_') != std::string::npos) {
+                char buf[200];
+                snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": invalid syntax", tok.c_str());
+                return fail(c, MNW_E_DOMAIN, buf);
+            }
+            if (isinf(v) && (tok.find('n') == std::string::npos && tok.find('N') == std::string::npos)) {
+                char buf[200];                                 // ParseFloat returns ErrRange, which the reference panics on
+                snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": value out of range", tok.c_str());
+                return fail(c, MNW_E_DOMAIN, buf);
+            }
+            const float f = (float)v;                         // float32(x): beyond float32's range becomes +-Inf as in Go
+            HIPCHK(c, hipMemcpy(float_out[w.slot] + w.row, &f, sizeof f, hipMemcpyHostToDevice));
+        }
+    }
+    return MNW_OK;
+}
 
 // ---- raw bit.Array on device buffers ----------------------------------------------------------
 int mnw_pack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint64_t* x, int64_t n, int bits, uint8_t* out, int64_t cap) {

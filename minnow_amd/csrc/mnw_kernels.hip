@@ -1823,6 +1823,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict
 
 #include "mnw_subcell.hip"
 #include "mnw_minh.hip"
+#include "mnw_text.hip"
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)

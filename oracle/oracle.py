@@ -357,3 +357,36 @@ def go_log10(x):
 
 def go_pow(x, y):
     return float(lib().mnwo_go_pow(float(x), float(y)))
+
+
+# ---- text catalogue ingest (go/text/text.go:176-197, go/text/parse.go) ---------------------------------
+def text_block_parse(data, sep, comm, float_cols, int_cols):
+    """text.Reader.Block after the read, restated: split at '\\n' (parse.go:15-36), uncomment (43-63), trim (66-78),
+    fields (172-211), strconv.Atoi / float32(strconv.ParseFloat(s, 64)).  Python's int() and float() stand in for Atoi
+    and ParseFloat: both conversions are exact / correctly rounded, hence unique, for well-formed decimal literals.
+    Returns (float columns, int columns) as lists of numpy arrays.  Raises ValueError where the reference panics."""
+    sep_b, comm_b = bytes([sep]), bytes([comm])
+    lines = bytes(data).split(b"\n")
+    lines = [ln.split(comm_b, 1)[0] for ln in lines]
+    lines = [ln for ln in lines if ln.strip(sep_b) != b""]
+    fout = [np.empty(len(lines), dtype=np.float32) for _ in float_cols]
+    iout = [np.empty(len(lines), dtype=np.int64) for _ in int_cols]
+    if not lines:
+        return fout, iout
+    buf_len = len(lines[0].split())                     # bytes.Fields: white space
+    want = list(float_cols) + list(int_cols)
+    if want and max(want) >= buf_len:
+        raise ValueError("Data has %d columns, but column %d was requested." % (buf_len, max(want)))
+    for i, ln in enumerate(lines):
+        words = [w for w in ln.split(sep_b) if w != b""]
+        if len(words) != buf_len:
+            raise ValueError("Data on line %d has %d columns, not %d." % (i + 1, len(words), buf_len))
+        for k, c in enumerate(float_cols):
+            with np.errstate(over="ignore"):                       # float32(x) beyond float32's range is +-Inf in Go too
+                fout[k][i] = np.float32(float(words[c].decode("ascii")))
+        for k, c in enumerate(int_cols):
+            v = int(words[c].decode("ascii"))
+            if not -2**63 <= v < 2**63:
+                raise ValueError("strconv.Atoi: value out of range")
+            iout[k][i] = v
+    return fout, iout

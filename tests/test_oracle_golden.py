@@ -267,3 +267,23 @@ def test_minh_go_log10_pow_restatement_is_plausible(oracle):
     for y in rng.uniform(-300, 300, 4000):
         assert abs(oracle.go_pow(10, y) / 10 ** y - 1) < 2e-15
     assert oracle.go_pow(10, float("inf")) == float("inf") and oracle.go_pow(10, float("-inf")) == 0 and math.isnan(oracle.go_pow(10, float("nan")))
+
+
+# ---- text ingest (go/text) -------------------------------------------------------------------------------
+def test_text_block_parse_reference_test(oracle):
+    """TestReader of go/text/text_test.go:66-127: names 1..4, out = columns "4","1","2","3" as f32, i64, f32, i64"""
+    text = b"""#123456789012345678
+#123456789012345678
+1    2     3      5
+11  12    13     15
+21  22    23     25
+31  32    33     35
+41  42    43     45
+"""
+    f, i = oracle.text_block_parse(text, ord(" "), ord("#"), [3, 1], [0, 2])
+    assert list(f[0]) == [5, 15, 25, 35, 45] and list(f[1]) == [2, 12, 22, 32, 42]
+    assert list(i[0]) == [1, 11, 21, 31, 41] and list(i[1]) == [3, 13, 23, 33, 43]
+    with pytest.raises(ValueError):
+        oracle.text_block_parse(b"1 2 3\n4 5\n", ord(" "), ord("#"), [0], [])
+    f, i = oracle.text_block_parse(b"1 2 # c\n\n  \n3 4", ord(" "), ord("#"), [1], [0])
+    assert list(f[0]) == [2, 4] and list(i[0]) == [1, 3]

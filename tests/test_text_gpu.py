@@ -1,0 +1,147 @@
+"""Text catalogue ingest (go/text/text.go:176-197, go/text/parse.go) against the oracle's restatement:
+the reference's own TestReader text (go/text/text_test.go:66-127), random Rockstar-like catalogues, decimal literals
+that need the correctly rounded slow path, comments and blank lines, and the inputs the reference panics on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mnw():
+    import minnow_amd
+    from minnow_amd import build as b
+    b.build()
+    if minnow_amd.device_count() < 1:
+        pytest.fail("no HIP device: GPU tests need a real MI355X (no CPU fallback exists)")
+    return minnow_amd
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _parse(mnw, torch, ctx, data, sep, comm, fcols, icols, cap=None):
+    dev = torch.device("cuda:0")
+    cap = cap if cap is not None else data.count(b"\n") + 2
+    fo = [torch.full((cap,), float("nan"), dtype=torch.float32, device=dev) for _ in fcols]
+    io = [torch.full((cap,), -7, dtype=torch.int64, device=dev) for _ in icols]
+    torch.cuda.synchronize()
+    n = ctx.text_parse(data, sep, comm, fcols, [t.data_ptr() for t in fo], icols, [t.data_ptr() for t in io], cap)
+    torch.cuda.synchronize()
+    return n, [t[:n].cpu().numpy() for t in fo], [t[:n].cpu().numpy() for t in io]
+
+
+def _check(mnw, torch, ctx, oracle, data, sep, comm, fcols, icols):
+    n, fo, io = _parse(mnw, torch, ctx, data, sep, comm, fcols, icols)
+    rf, ri = oracle.text_block_parse(data, sep, comm, fcols, icols)
+    assert n == (rf[0].size if rf else ri[0].size)
+    for a, b in zip(fo, rf):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) or np.array_equal(a, b, equal_nan=True)
+    for a, b in zip(io, ri):
+        assert np.array_equal(a, b)
+    return n
+
+
+def test_reference_reader_text(mnw, oracle, torch_mod):
+    """TestReader of go/text/text_test.go: columns "4", "1", "2", "3" as float32, int64, float32, int64; the two
+    blocks of the reference test (block size 120) and the whole text at once"""
+    text = b"""#123456789012345678
+#123456789012345678
+1    2     3      5
+11  12    13     15
+21  22    23     25
+31  32    33     35
+41  42    43     45
+"""
+    with mnw.Context(0) as c:
+        n, fo, io = _parse(mnw, torch_mod, c, text, ord(" "), ord("#"), [3, 1], [0, 2])
+        assert n == 5
+        assert list(fo[0]) == [5, 15, 25, 35, 45] and list(fo[1]) == [2, 12, 22, 32, 42]
+        assert list(io[0]) == [1, 11, 21, 31, 41] and list(io[1]) == [3, 13, 23, 33, 43]
+        # the reference's blocks: findBlocks cuts at the first newline at or after byte 120 - 50 (text.go:101-127)
+        cut = text.index(b"\n", 70) + 1
+        n1, fo1, io1 = _parse(mnw, torch_mod, c, text[:cut], ord(" "), ord("#"), [3, 1], [0, 2])
+        n2, fo2, io2 = _parse(mnw, torch_mod, c, text[cut:], ord(" "), ord("#"), [3, 1], [0, 2])
+        assert (n1, n2) == (2, 3)
+        assert list(fo1[0]) == [5, 15] and list(io1[0]) == [1, 11] and list(fo2[0]) == [25, 35, 45] and list(io2[1]) == [23, 33, 43]
+
+
+def test_random_catalogues(mnw, oracle, torch_mod):
+    rng = np.random.default_rng(71)
+    with mnw.Context(0) as c:
+        for trial, (rows, ncol, sep) in enumerate([(1, 3, " "), (257, 5, " "), (5000, 44, " "), (20000, 12, " "), (70000, 8, "\t")]):
+            lines = ["#id mass x y z flag" + " pad" * 3, "# second header line"]
+            for r in range(rows):
+                w = []
+                for k in range(ncol):
+                    kind = k % 4
+                    if kind == 0:
+                        w.append(str(int(rng.integers(-10**12, 10**12))))
+                    elif kind == 1:
+                        w.append("%.6e" % (10 ** rng.uniform(8, 15)))
+                    elif kind == 2:
+                        w.append("%.5f" % rng.uniform(0, 250))
+                    else:
+                        w.append("%g" % rng.normal(0, 300))
+                pad = sep * int(rng.integers(1, 4)) if sep == " " else sep
+                ln = (sep * int(rng.integers(0, 3)) if sep == " " else "") + pad.join(w)
+                if rng.random() < 0.02:
+                    ln += " # trailing comment"
+                lines.append(ln)
+                if rng.random() < 0.01:
+                    lines.append(sep * int(rng.integers(0, 5)))           # blank or separator-only line: dropped
+            data = ("\n".join(lines) + ("\n" if trial % 2 == 0 else "")).encode()
+            if sep != " ":
+                data = data.replace(b" # trailing comment", b"# trailing comment")
+            fcols = [k for k in range(ncol) if k % 4 != 0][:40]
+            icols = [k for k in range(ncol) if k % 4 == 0][:40]
+            n = _check(mnw, torch_mod, c, oracle, data, ord(sep), ord("#"), fcols, icols)
+            assert n == rows
+        # a separator that is not white space: the reference counts the words of the first line with bytes.Fields
+        # (parse.go:96) and panics on any request beyond that single "word"; so do the oracle and the library
+        with pytest.raises(ValueError):
+            oracle.text_block_parse(b"1,2,3\n4,5,6\n", ord(","), ord("#"), [1], [0])
+        with pytest.raises(mnw.MnwError):
+            _parse(mnw, torch_mod, c, b"1,2,3\n4,5,6\n", ord(","), ord("#"), [1], [0])
+
+
+def test_hard_float_literals(mnw, oracle, torch_mod):
+    """literals outside the device's exact fast path (more than 15-19 digits, exponents beyond 10^+-22, subnormals,
+    halfway cases of the float64 and of the float32 rounding, inf/nan spellings): converted on the host with strtod"""
+    toks = ["0", "-0", "0.0", "1", "-1.5", "+2.5", "1e22", "1e23", "9007199254740993", "9007199254740992", "123456789012345678901234567890",
+            "0.1", "0.3", "1.7976931348623157e308", "4.9e-324", "2.2250738585072014e-308", "1e-45", "1.401298464324817e-45",
+            "7.006492321624085e-46", "3.4028234663852886e38", "3.4028235677973366e38", "3.4028235677973367e38", "1e39",
+            "16777217", "16777217.0000000001", "0.000000000000000000000000000000000000000000001", "1.00000017881393432617187500001",
+            "1.000000178813934326171875", "8.5", ".5", "5.", "1E5", "1e+5", "1e-5", "inf", "-Inf", "+infinity", "nan", "NaN",
+            "123456.789e3", "0.00001e-20", "179769313486231570000000000000000000000e270"]
+    rng = np.random.default_rng(5)
+    toks += ["%.17g" % v for v in rng.standard_normal(300) * 10.0 ** rng.integers(-30, 30, 300)]
+    toks += ["%d.%018d" % (rng.integers(0, 10**6), rng.integers(0, 10**18)) for _ in range(200)]
+    data = "\n".join("%d %s" % (i, t) for i, t in enumerate(toks)).encode()
+    with mnw.Context(0) as c:
+        n = _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0])
+        assert n == len(toks)
+
+
+def test_reference_panics_become_errors(mnw, torch_mod):
+    cases = {
+        b"1 2 3\n4 5\n": "columns",                      # a line with another number of fields (parse.go:114-118)
+        b"1 2 3\n4 x 6\n": "Atoi",                       # strconv.Atoi fails
+        b"1 2 3\n4 5 6.5.1\n": "ParseFloat",             # strconv.ParseFloat fails
+        b"1 2 3\n4 99999999999999999999 6\n": "Atoi",    # out of int64's range
+        b"1 2 3\n4 5 1e999\n": "range",                  # ParseFloat's ErrRange
+    }
+    with mnw.Context(0) as c:
+        for data, what in cases.items():
+            with pytest.raises(mnw.MnwError) as e:
+                _parse(mnw, torch_mod, c, data, ord(" "), ord("#"), [2], [1])
+            assert what in str(e.value), (data, str(e.value))
+        with pytest.raises(mnw.MnwError) as e:             # a requested column the data does not have (parse.go:98-103)
+            _parse(mnw, torch_mod, c, b"1 2 3\n", ord(" "), ord("#"), [5], [])
+        assert "column 5 was requested" in str(e.value)
+        n, fo, io = _parse(mnw, torch_mod, c, b"# only comments\n\n   \n", ord(" "), ord("#"), [0], [])
+        assert n == 0
