@@ -237,6 +237,10 @@ int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t se
                    const int32_t *float_cols, int n_float, float *const *float_out,
                    const int32_t *int_cols, int n_int, int64_t *const *int_out,
                    int64_t capacity_rows, int64_t *n_rows);
+/* Of the last mnw_text_parse: out[0] = lines (split()'s tokens), out[1] = lines kept, out[2] = 12 KB tiles of text that
+ * took the general one-thread-per-line path (a comment character or an overlong line in reach) instead of the
+ * one-thread-per-field path. */
+int mnw_text_stats(mnw_ctx *ctx, int64_t out[3]);
 
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */
@@ -265,8 +269,8 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_UNPACK_VEC3 13  /* minp vectors without staging: the three streams of a sub-cell into the grid */
 #define MNW_K_MINH_PROCESS 14 /* minh processFloatGroup over device columns */
 #define MNW_K_MINH_UNLOG  15  /* minh reader: 10^x */
-#define MNW_K_TEXT_LINES  16  /* text ingest: newline count + line starts + kept-line flags */
-#define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers, one thread per line */
+#define MNW_K_TEXT_LINES  16  /* text ingest: lines and kept lines per tile + prefix (k_text_count, k_text_scan) */
+#define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers (k_text_parse) */
 #define MNW_K_COUNT       18
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */

@@ -91,6 +91,7 @@ SIGNATURES = {
     "mnw_minh_selftest": (_int, [_p, _int, _u64, _u64, C.POINTER(_u64)]),
     "mnw_text_parse": (_int, [_p, _p, _i64, C.c_uint8, C.c_uint8, C.POINTER(C.c_int32), _int, C.POINTER(_p),
                               C.POINTER(C.c_int32), _int, C.POINTER(_p), _i64, C.POINTER(_i64)]),
+    "mnw_text_stats": (_int, [_p, C.POINTER(_i64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),

@@ -247,6 +247,12 @@ class Context:
                                            capacity_rows, C.byref(n)))
         return n.value
 
+    def text_stats(self):
+        """of the last text_parse: (lines, lines kept, tiles on the general path)"""
+        out = (C.c_int64 * 3)()
+        self._check(self._L.mnw_text_stats(self._h, out))
+        return tuple(out)
+
     def pack_u64_dev(self, x_ptr, n, bits, out_ptr, cap, stream=None):
         self._check(self._L.mnw_pack_u64_dev(self._h, stream, x_ptr, n, bits, out_ptr, cap))
 

@@ -43,15 +43,13 @@ struct MinhArgs { MinhCol col[kMinhBatch]; };
 void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_selftest(hipStream_t, int, uint64_t, uint64_t, unsigned long long*);
-constexpr int kTextTile = 16384, kTextMaxCols = 256, kTextMaxOut = 48;
+constexpr int kTextTile = 12288, kTextMaxCols = 256, kTextMaxOut = 48;
 struct TextCols { int16_t slot[kTextMaxCols]; float* fout[kTextMaxOut]; int64_t* iout[kTextMaxOut]; int32_t fields_expected; int32_t max_field; };
 struct TextSlow { int64_t row; int64_t offset; int32_t len; int32_t slot; };
-struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned int pad; };
-void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint32_t*);
-void launch_text_lines(hipStream_t, const uint8_t*, int64_t, const int64_t*, int64_t*);
-void launch_text_valid(hipStream_t, const uint8_t*, const int64_t*, int64_t, uint8_t, uint8_t, uint8_t*, uint32_t*);
-void launch_text_parse(hipStream_t, const uint8_t*, const int64_t*, int64_t, uint8_t, uint8_t, const uint8_t*, const int64_t*, const TextCols&,
-                       TextSlow*, unsigned, TextState*);
+struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned int flags; long long n_rows; long long n_lines; unsigned int tiles_general; unsigned int pad; };
+void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, int64_t*);
+void launch_text_scan(hipStream_t, int64_t*, int64_t, TextState*);
+void launch_text_parse(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, const int64_t*, const TextCols&, int64_t, TextSlow*, unsigned, TextState*);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -136,9 +134,10 @@ struct mnw_ctx {
     float* d_xf = nullptr;
 
     // text ingest scratch (grow-only): the text, line starts, kept-line flags, per-tile counts and bases, slow list
-    size_t cap_text = 0, cap_lines = 0, cap_valid = 0, cap_tile = 0, cap_tbase = 0;
-    void* d_text = nullptr; void* d_lines = nullptr; void* d_valid = nullptr; void* d_tile = nullptr; void* d_tbase = nullptr;
+    size_t cap_text = 0, cap_tile = 0;
+    void* d_text = nullptr; void* d_tile = nullptr;
     void* d_tslow = nullptr; void* d_tstate = nullptr;
+    int64_t text_stats[3] = {0, 0, 0};              // of the last mnw_text_parse: lines, lines kept, tiles on the general path
 
     // exact path scratch
     size_t cap_q = 0;
@@ -700,7 +699,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_UNPACK_VEC3: return "k_unpack_vec3";
         case MNW_K_MINH_PROCESS: return "k_minh_process";
         case MNW_K_MINH_UNLOG: return "k_minh_unlog";
-        case MNW_K_TEXT_LINES: return "k_text_lines";
+        case MNW_K_TEXT_LINES: return "k_text_count+k_text_scan";
         case MNW_K_TEXT_PARSE: return "k_text_parse";
         default: return "";
     }
@@ -739,7 +738,7 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     if (c->d_recs) hipFree(c->d_recs);
     if (c->d_soa) hipFree(c->d_soa);
     if (c->d_xf) hipFree(c->d_xf);
-    for (void* q : {c->d_text, c->d_lines, c->d_valid, c->d_tile, c->d_tbase, c->d_tslow, c->d_tstate}) if (q) hipFree(q);
+    for (void* q : {c->d_text, c->d_tile, c->d_tslow, c->d_tstate}) if (q) hipFree(q);
     if (c->d_bkeys) hipFree(c->d_bkeys);
     if (c->h_bkeys) hipHostFree(c->h_bkeys);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1330,62 +1329,6 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
         else { if (!int_out[k - n_float]) return fail(c, MNW_E_ARG, "text: null output"); cols.slot[f] = (int16_t)(0x4000 + k - n_float); cols.iout[k - n_float] = int_out[k - n_float]; }
         if (f > cols.max_field) cols.max_field = f;
     }
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
-    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
-    if (rc) return rc;
-    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 4 + 16);
-    if (rc) return rc;
-    rc = ensure_dev(c, &c->d_tbase, &c->cap_tbase, (size_t)tiles * 8 + 16);
-    if (rc) return rc;
-    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
-    if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
-    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
-    const uint8_t* dtext = (const uint8_t*)c->d_text;
-    // ---- lines --------------------------------------------------------------------------------------------
-    std::vector<uint32_t> tcount((size_t)tiles);
-    std::vector<int64_t> tbase((size_t)tiles);
-    int64_t nl = 0;
-    {
-        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
-        mnw::launch_text_count(s, dtext, nbytes, (uint32_t*)c->d_tile);
-    }
-    HIPCHK(c, hipMemcpyAsync(tcount.data(), c->d_tile, (size_t)tiles * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int64_t t = 0; t < tiles; ++t) { tbase[(size_t)t] = nl; nl += tcount[(size_t)t]; }
-    const int64_t nlines = nl + 1;                                  // split(): n + 1 tokens, parse.go:22
-    rc = ensure_dev(c, &c->d_lines, &c->cap_lines, (size_t)(nlines + 1) * 8);
-    if (rc) return rc;
-    rc = ensure_dev(c, &c->d_valid, &c->cap_valid, (size_t)nlines + 16);
-    if (rc) return rc;
-    int64_t* dlines = (int64_t*)c->d_lines;
-    const int64_t first = 0, last = nbytes + 1;
-    HIPCHK(c, hipMemcpyAsync(dlines, &first, 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(dlines + nlines, &last, 8, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_tbase, tbase.data(), (size_t)tiles * 8, hipMemcpyHostToDevice, s));
-    {
-        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
-        mnw::launch_text_lines(s, dtext, nbytes, (const int64_t*)c->d_tbase, dlines);
-    }
-    // ---- kept lines -----------------------------------------------------------------------------------------
-    const int64_t vtiles = (nlines + 255) / 256;
-    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)vtiles * 4 + 16);
-    if (rc) return rc;
-    rc = ensure_dev(c, &c->d_tbase, &c->cap_tbase, (size_t)vtiles * 8 + 16);
-    if (rc) return rc;
-    {
-        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
-        mnw::launch_text_valid(s, dtext, dlines, nlines, sep, comment, (uint8_t*)c->d_valid, (uint32_t*)c->d_tile);
-    }
-    tcount.resize((size_t)vtiles); tbase.resize((size_t)vtiles);
-    HIPCHK(c, hipMemcpyAsync(tcount.data(), c->d_tile, (size_t)vtiles * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    int64_t rows = 0;
-    for (int64_t t = 0; t < vtiles; ++t) { tbase[(size_t)t] = rows; rows += tcount[(size_t)t]; }
-    *n_rows = rows;
-    if (rows == 0) return MNW_OK;
-    if (rows > capacity_rows) return fail(c, MNW_E_CAPACITY, "text: more lines than capacity_rows");
     // bufLen = len(bytes.Fields(lines[0])) (parse.go:96): words of the first kept line, split at white space
     {
         int64_t p = 0;
@@ -1404,6 +1347,7 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             }
             p = e + 1;
         }
+        if (words < 0) return MNW_OK;                               // nothing but comments and blank lines
         cols.fields_expected = words;
         if (cols.max_field >= words) {
             char buf[160];
@@ -1411,18 +1355,38 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             return fail(c, MNW_E_DOMAIN, buf);
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_tbase, tbase.data(), (size_t)vtiles * 8, hipMemcpyHostToDevice, s));
-    mnw::TextState st0 = {~0ull, 0u, 0u};
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
+    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
+    if (rc) return rc;
+    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
+    if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
+    mnw::TextState st0;
+    memset(&st0, 0, sizeof st0);
+    st0.err_line = ~0ull;
     HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    const uint8_t* dtext = (const uint8_t*)c->d_text;
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
+        mnw::launch_text_count(s, dtext, nbytes, sep, comment, (int64_t*)c->d_tile);
+        mnw::launch_text_scan(s, (int64_t*)c->d_tile, tiles, (mnw::TextState*)c->d_tstate);
+    }
     {
         ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
-        mnw::launch_text_parse(s, dtext, dlines, nlines, sep, comment, (const uint8_t*)c->d_valid, (const int64_t*)c->d_tbase, cols,
+        mnw::launch_text_parse(s, dtext, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
                                (mnw::TextSlow*)c->d_tslow, kTextSlowCap, (mnw::TextState*)c->d_tstate);
     }
     HIPCHK(c, hipGetLastError());
     mnw::TextState st;
     HIPCHK(c, hipMemcpyAsync(&st, c->d_tstate, sizeof st, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    c->text_stats[0] = st.n_lines; c->text_stats[1] = st.n_rows; c->text_stats[2] = st.tiles_general;
+    *n_rows = st.n_rows;
+    if (st.n_rows > capacity_rows || (st.flags & 1u)) return fail(c, MNW_E_CAPACITY, "text: more lines than capacity_rows");
     if (st.err_line != ~0ull) {
         char buf[200];
         const long long line = (long long)(st.err_line >> 8);
@@ -1456,6 +1420,12 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             HIPCHK(c, hipMemcpy(float_out[w.slot] + w.row, &f, sizeof f, hipMemcpyHostToDevice));
         }
     }
+    return MNW_OK;
+}
+
+int mnw_text_stats(mnw_ctx* c, int64_t out[3]) {
+    if (!c || !out) return MNW_E_ARG;
+    for (int k = 0; k < 3; ++k) out[k] = c->text_stats[k];
     return MNW_OK;
 }
 

@@ -3,10 +3,20 @@
 // ("data # comment"), drops lines that hold nothing but separators, breaks every line into fields at runs of the
 // separator byte and runs strconv.Atoi / float32(strconv.ParseFloat(s, 64)) on the requested fields.
 //
-//   k_text_count   newlines per 16 KB tile                        (host: exclusive prefix over the tiles)
-//   k_text_lines   start offset of every line                     line i = [start[i], start[i+1] - 1)
-//   k_text_valid   which lines survive uncomment + trim, count per 256 lines   (host: prefix again)
-//   k_text_parse   one thread per line: fields, numbers, written at the line's compacted row
+// The text is cut into tiles of 12,288 bytes; a tile OWNS the lines that start inside it (wherever they end).
+//
+//   k_text_count   per tile: lines owned, owned lines that survive uncomment + trim
+//   k_text_scan    exclusive prefix over the tiles (one workgroup): first line number and first output row of every tile
+//   k_text_parse   per tile: 16 KB of text (16 bytes before the tile, the tile, 4,080 bytes after it for the end of its
+//                  last line) go to LDS; every thread turns its 64 bytes into three 64-bit masks (newline, separator,
+//                  comment) and from then on lines and fields are bit arithmetic: field starts = content bits whose
+//                  predecessor is no content; the line of a field = newlines before it (prefix sum over the threads);
+//                  its number inside the line = field starts since the last newline (a segmented prefix sum); its output
+//                  row = owned non-empty lines that ended before it (prefix sum).  Wanted fields are put on a list in LDS
+//                  and converted ONE FIELD PER THREAD, so the lanes stay busy whatever the lines look like.
+//                  A tile that holds a comment character, a line that does not end inside the staged text, more than
+//                  2,048 kept lines or more wanted fields than the list holds takes the general path: one thread per
+//                  line, walking it byte by byte as the reference does.
 //
 // Numbers: a decimal literal whose digits fit 2^53 and whose power of ten is within 10^+-22 is converted with ONE
 // correctly rounded float64 multiplication or division of two exactly representable values (Clinger's fast path), so
@@ -15,7 +25,11 @@
 // is put on a list and converted on the host with strtod, which is correctly rounded as well.
 // (This file is included by mnw_kernels.hip, inside namespace mnw.)
 
-constexpr int kTextTile = 16384;          // bytes per workgroup in the line passes: 256 threads x 64 bytes
+constexpr int kTextTile = 12288;          // bytes of text whose line starts one workgroup owns
+constexpr int kTextRegion = 16384;        // bytes a workgroup stages: 256 threads x 64
+constexpr int kTextLead = 16;             // staged bytes in front of the tile (the byte before the tile decides whether a line starts at its first byte)
+constexpr int kTextRecCap = 3072;         // wanted fields per tile on the fast path
+constexpr int kTextMaxRowOff = 2048;      // kept lines per tile on the fast path (11 bits of a record)
 constexpr int kTextMaxCols = 256;         // fields per line that can be addressed
 constexpr int kTextMaxOut = 48;           // requested columns of each type
 
@@ -37,112 +51,151 @@ struct TextSlow {                         // a literal the device did not conver
 struct TextState {                        // device words the host reads back
     unsigned long long err_line;          // lowest (raw line index + 1) << 8 | code, ~0 = none
     unsigned int n_slow;
+    unsigned int flags;                   // 1: a row beyond capacity_rows was dropped
+    long long n_rows;                     // lines kept
+    long long n_lines;                    // lines
+    unsigned int tiles_general;           // tiles that took the general path (diagnostic)
     unsigned int pad;
 };
 constexpr int kTextErrFields = 1;         // wrong number of fields
 constexpr int kTextErrInt = 2;            // strconv.Atoi would fail
 constexpr int kTextErrFloat = 3;          // strconv.ParseFloat would fail
 
-__device__ __forceinline__ int count_byte16(const u32x4 v, uint32_t pat) {
-    int c = 0;
+// 4 bits: which bytes of w equal the byte replicated in pat
+__device__ __forceinline__ uint32_t text_eq4(uint32_t w, uint32_t pat) {
+    const uint32_t x = w ^ pat;                                                      // zero bytes where the byte matches
+    const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);       // 0x80 in every zero byte, exactly
+    return (z * 0x00204081u) >> 28;                                                  // bits 7,15,23,31 -> 0,1,2,3 (no carries: the partial products are disjoint)
+}
+__device__ __forceinline__ uint64_t text_eq_mask(const u32x4 (&w)[4], uint8_t c) {
+    const uint32_t pat = 0x01010101u * c;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            lo |= text_eq4(w[k][d], pat) << (16 * k + 4 * d);
+            hi |= text_eq4(w[k + 2][d], pat) << (16 * k + 4 * d);
+        }
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t bits_from(int lo) { return lo <= 0 ? ~0ull : lo > 63 ? 0ull : ~0ull << lo; }          // bits >= lo
+__device__ __forceinline__ uint64_t bits_upto(int hi) { return hi < 0 ? 0ull : hi >= 63 ? ~0ull : ~0ull >> (63 - hi); }    // bits <= hi
+__device__ __forceinline__ uint64_t bits_below(int b) { return (1ull << b) - 1; }                                          // bits < b, 0 <= b <= 63
+
+// the 64 bytes at text[a, a + 64), a a multiple of 16; bytes in front of the text and behind its end read as '\n'
+// (the buffer is padded, so a 16-byte load that starts inside the text is always legal)
+__device__ __forceinline__ void text_load_chunk(const uint8_t* __restrict__ text, int64_t n, int64_t a, u32x4 (&w)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t x = v[k] ^ pat;                                  // zero bytes where the byte matches
-        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte
-        c += __popc(z);
+        const int64_t q = a + 16 * k;
+        if (q >= 0 && q + 16 <= n) w[k] = ldg<u32x4>(text + q);
+        else {
+            u32x4 v = {0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au};
+            if (q >= 0 && q < n) {
+                const u32x4 g = ldg<u32x4>(text + q);
+                const int keep = (int)(n - q);                                          // 1..15 bytes of text
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int kd = keep - 4 * d;
+                    const uint32_t m = kd >= 4 ? ~0u : kd <= 0 ? 0u : (1u << (8 * kd)) - 1u;
+                    v[d] = (g[d] & m) | (0x0a0a0a0au & ~m);
+                }
+            }
+            w[k] = v;
+        }
     }
-    return c;
 }
 
-__global__ __launch_bounds__(256) void k_text_count(const uint8_t* __restrict__ text, int64_t n, uint32_t* __restrict__ tile_nl) {
-    __shared__ int red[4];
-    const int64_t p0 = (int64_t)blockIdx.x * kTextTile + threadIdx.x * 64;
-    int c = 0;
-    if (p0 + 64 <= n) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c += count_byte16(ldg<u32x4>(text + p0 + 16 * k), 0x0a0a0a0au);
-    } else {
-        for (int64_t p = p0; p < n; ++p) c += text[p] == '\n';
+// does the line that starts at s survive uncomment() and trim() (parse.go:43-78)?
+__device__ __forceinline__ bool text_line_valid(const uint8_t* __restrict__ text, int64_t s, int64_t n, uint8_t sep, uint8_t comm) {
+    for (int64_t p = s; p < n; ++p) {
+        const uint8_t c = text[p];
+        if (c == '\n' || c == comm) return false;
+        if (c != sep) return true;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane_id() == 0) red[wave_id()] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_nl[blockIdx.x] = (uint32_t)(red[0] + red[1] + red[2] + red[3]);
+    return false;
 }
 
-// exclusive prefix of a per-thread count over the 256 threads of a workgroup
-__device__ __forceinline__ int block_exclusive_scan(int v, int* wsum) {
+// exclusive prefix of a per-thread count over the 256 threads of a workgroup, and the total
+__device__ __forceinline__ int block_exclusive_scan(int v, int* wsum, int* total) {
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
+    __syncthreads();                                   // the previous use of wsum is over
     if (lane_id() == 63) wsum[wave_id()] = incl;
     __syncthreads();
     int base = 0;
     for (int w = 0; w < wave_id(); ++w) base += wsum[w];
-    __syncthreads();
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_text_lines(const uint8_t* __restrict__ text, int64_t n, const int64_t* __restrict__ tile_base,
-                                                    int64_t* __restrict__ line_start) {
-    __shared__ int wsum[4];
-    const int64_t p0 = (int64_t)blockIdx.x * kTextTile + threadIdx.x * 64;
-    const int64_t p1 = p0 + 64 < n ? p0 + 64 : n;
-    // the thread's 64 bytes, once, as four 16-byte vectors (zero past the end: never a newline)
-    u32x4 w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (p0 + 16 * k + 16 <= n) w[k] = ldg<u32x4>(text + p0 + 16 * k);
-        else {
-            w[k] = u32x4{0, 0, 0, 0};
-            for (int64_t p = p0 + 16 * k; p < p1; ++p) w[k][(int)(p - p0 - 16 * k) >> 2] |= (uint32_t)text[p] << (8 * ((p - p0) & 3));
-        }
-    }
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c += count_byte16(w[k], 0x0a0a0a0au);
-    int64_t idx = tile_base[blockIdx.x] + block_exclusive_scan(c, wsum);
-    if (c) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t word = w[k][d];
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (((word >> (8 * b)) & 0xffu) == '\n') line_start[++idx] = p0 + 16 * k + 4 * d + b + 1;   // line idx starts behind the idx-th newline
-            }
-        }
-    }
+// which newlines of the thread's chunk start a line the tile owns: line starts in [T0, T0 + kTextTile), i.e. newlines at
+// region offsets 15 .. kTextLead + kTextTile - 2, and inside the text (the fill behind the end is not a line start)
+__device__ __forceinline__ uint64_t text_own_mask(uint64_t nl, int t, int64_t R, int64_t n) {
+    const int64_t hi_abs = n - 1 - R;
+    const int hi = (int)(hi_abs < kTextLead + kTextTile - 2 ? hi_abs : kTextLead + kTextTile - 2);
+    return nl & bits_from(kTextLead - 1 - 64 * t) & bits_upto(hi - 64 * t);
 }
 
-// [s, e) of raw line i with its comment cut off (parse.go:43-63)
-__device__ __forceinline__ void text_line_span(const uint8_t* __restrict__ text, const int64_t* __restrict__ line_start, int64_t i,
-                                               uint8_t comm, int64_t* s, int64_t* e) {
-    const int64_t a = line_start[i], b = line_start[i + 1] - 1;
-    int64_t p = a;
-    while (p < b && text[p] != comm) ++p;
-    *s = a; *e = p;
-}
-
-__global__ __launch_bounds__(256) void k_text_valid(const uint8_t* __restrict__ text, const int64_t* __restrict__ line_start, int64_t nlines,
-                                                    uint8_t sep, uint8_t comm, uint8_t* __restrict__ valid, uint32_t* __restrict__ tile_valid) {
-    __shared__ int red[4];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int v = 0;
-    if (i < nlines) {
-        int64_t s, e;
-        text_line_span(text, line_start, i, comm, &s, &e);
-        for (int64_t p = s; p < e; ++p) if (text[p] != sep) { v = 1; break; }       // trim(), parse.go:66-78
-        valid[i] = (uint8_t)v;
+__global__ __launch_bounds__(256) void k_text_count(const uint8_t* __restrict__ text, int64_t n, uint8_t sep, uint8_t comm,
+                                                    int64_t* __restrict__ tile_cnt) {
+    __shared__ int red[8];
+    const int t = threadIdx.x;
+    const int64_t R = (int64_t)blockIdx.x * kTextTile - kTextLead;
+    int c_nl = 0, c_valid = 0;
+    if (64 * t <= kTextLead + kTextTile - 2) {
+        u32x4 w[4];
+        text_load_chunk(text, n, R + 64 * t, w);
+        const uint64_t nl = text_eq_mask(w, '\n'), sp = text_eq_mask(w, sep), cm = text_eq_mask(w, comm);
+        const uint64_t own = text_own_mask(nl, t, R, n);
+        c_nl = __popcll(own);
+        const uint64_t next = own << 1;                               // the first byte of each owned line (bit 63's is in the next chunk)
+        c_valid = __popcll(next & ~(nl | cm | sp));                   // content: kept
+        uint64_t walk = next & sp & ~(nl | cm);                       // a separator: look further
+        while (walk) {
+            const int b = __builtin_ctzll(walk);
+            walk &= walk - 1;
+            c_valid += text_line_valid(text, R + 64 * t + b, n, sep, comm);
+        }
+        if (own >> 63) c_valid += text_line_valid(text, R + 64 * t + 64, n, sep, comm);
     }
-    int c = v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane_id() == 0) red[wave_id()] = c;
+    for (int o = 32; o > 0; o >>= 1) { c_nl += __shfl_xor(c_nl, o); c_valid += __shfl_xor(c_valid, o); }
+    if (lane_id() == 0) { red[wave_id()] = c_nl; red[4 + wave_id()] = c_valid; }
     __syncthreads();
-    if (threadIdx.x == 0) tile_valid[blockIdx.x] = (uint32_t)(red[0] + red[1] + red[2] + red[3]);
+    if (t == 0) {
+        tile_cnt[2 * (int64_t)blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        tile_cnt[2 * (int64_t)blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// tile_cnt[2t], [2t+1] -> exclusive prefixes (first line number, first output row of tile t); totals to the state
+__global__ __launch_bounds__(1024) void k_text_scan(int64_t* __restrict__ tile_cnt, int64_t tiles, TextState* __restrict__ st) {
+    __shared__ long long wl[16], wr[16];
+    const int t = threadIdx.x;
+    const int64_t per = (tiles + 1023) / 1024;
+    const int64_t a = t * per, b = a + per < tiles ? a + per : tiles;
+    long long sl = 0, sr = 0;
+    for (int64_t k = a; k < b; ++k) { sl += tile_cnt[2 * k]; sr += tile_cnt[2 * k + 1]; }
+    long long il = sl, ir = sr;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long tl = __shfl_up(il, o), tr = __shfl_up(ir, o);
+        if ((t & 63) >= o) { il += tl; ir += tr; }
+    }
+    if ((t & 63) == 63) { wl[t >> 6] = il; wr[t >> 6] = ir; }
+    __syncthreads();
+    long long bl = 0, br = 0;
+    for (int w = 0; w < (t >> 6); ++w) { bl += wl[w]; br += wr[w]; }
+    bl += il - sl; br += ir - sr;
+    for (int64_t k = a; k < b; ++k) {
+        const long long cl = tile_cnt[2 * k], cr = tile_cnt[2 * k + 1];
+        tile_cnt[2 * k] = bl; tile_cnt[2 * k + 1] = br;
+        bl += cl; br += cr;
+    }
+    if (t == 1023) { st->n_lines = bl; st->n_rows = br; }
 }
 
 __device__ __forceinline__ void text_error(TextState* st, int64_t line, int code) {
@@ -218,86 +271,208 @@ __device__ __forceinline__ int text_atof(const uint8_t* __restrict__ p, int len,
     return 0;
 }
 
-// Lines per workgroup (one wave) and the LDS budget for their text.  Sixty-four lines walked straight out of global
-// memory touch 64 different cache lines per load instruction and evict each other from the L1 long before a lane has
-// used up its line (measured: 20 GB/s of text); so the wave first copies the contiguous span of its 64 lines into
-// LDS with coalesced 16-byte loads and the lanes parse from there.  A span that does not fit (very long lines) is
-// parsed from global memory.
-constexpr int kTextLinesPerWG = 64;
-constexpr int kTextSpanMax = 60 * 1024;
+// one wanted field -> its output; tok[0, len) through a flat pointer (LDS or global)
+__device__ __forceinline__ void text_convert(const uint8_t* tok, int len, int sl, int64_t row, int64_t line, int64_t offset,
+                                             float* const* fout, int64_t* const* iout, int64_t capacity,
+                                             TextSlow* __restrict__ slow, unsigned int slow_cap, TextState* __restrict__ st) {
+    if (row >= capacity) { atomicOr(&st->flags, 1u); return; }
+    if (sl >= 0x4000) {
+        int64_t x;
+        if (text_atoi(tok, len, &x)) iout[sl - 0x4000][row] = x;
+        else text_error(st, line, kTextErrInt);
+    } else {
+        double x;
+        const int rc = text_atof(tok, len, &x);
+        if (rc == 0) fout[sl][row] = (float)x;                                      // float32(x), parse.go:165
+        else if (rc == 1) {
+            const unsigned k = atomicAdd(&st->n_slow, 1u);
+            if (k < slow_cap) { TextSlow w = {row, offset, (int32_t)len, sl}; slow[k] = w; }
+        } else text_error(st, line, kTextErrFloat);
+    }
+}
 
-__global__ __launch_bounds__(kTextLinesPerWG) void k_text_parse(const uint8_t* __restrict__ text, const int64_t* __restrict__ line_start,
-                                                                int64_t nlines, uint8_t sep, uint8_t comm, const uint8_t* __restrict__ valid,
-                                                                const int64_t* __restrict__ tile_vbase, TextCols cols,
-                                                                TextSlow* __restrict__ slow, unsigned int slow_cap, TextState* __restrict__ st) {
-    __shared__ __attribute__((aligned(16))) uint8_t span[kTextSpanMax];
-    const int64_t i0 = (int64_t)blockIdx.x * kTextLinesPerWG;
-    const int64_t i = i0 + threadIdx.x;
-    const int v = i < nlines ? (int)valid[i] : 0;
-    // the row of the line among the kept ones: tile_vbase is per 256 lines
-    int incl = v;
+__global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ text, int64_t n, uint8_t sep, uint8_t comm,
+                                                    const int64_t* __restrict__ tile_base, TextCols cols, int64_t capacity,
+                                                    TextSlow* __restrict__ slow, unsigned int slow_cap, TextState* __restrict__ st) {
+    __shared__ __attribute__((aligned(16))) uint8_t region[kTextRegion];
+    __shared__ uint32_t rec[kTextRecCap];
+    __shared__ int16_t s_slot[kTextMaxCols];
+    __shared__ float* s_fout[kTextMaxOut];
+    __shared__ int64_t* s_iout[kTextMaxOut];
+    __shared__ int wsum[4];
+    __shared__ uint32_t wseg[4];
+    __shared__ unsigned int s_nrec, s_flags, s_nown;
+
+    const int t = threadIdx.x;
+    const int64_t R = (int64_t)blockIdx.x * kTextTile - kTextLead;
+    const int64_t line_base = tile_base[2 * (int64_t)blockIdx.x], row_base = tile_base[2 * (int64_t)blockIdx.x + 1];
+    if (t == 0) { s_nrec = 0; s_flags = 0; s_nown = 0; }
+    s_slot[t] = cols.slot[t];
+    if (t < kTextMaxOut) { s_fout[t] = cols.fout[t]; s_iout[t] = cols.iout[t]; }
+    u32x4 w[4];
+    text_load_chunk(text, n, R + 64 * t, w);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += t; }
-    int64_t row = tile_vbase[i0 / 256] + incl - v;
-    for (int64_t q = i0 / 256 * 256; q < i0; q += 64) {          // kept lines of the earlier waves' worth of this 256-line tile
-        const int64_t j = q + threadIdx.x;
-        row += __popcll(__ballot(j < nlines && valid[j]));
-    }
-    const int64_t last = i0 + kTextLinesPerWG < nlines ? i0 + kTextLinesPerWG : nlines;
-    const int64_t g0 = line_start[i0] & ~(int64_t)15, g1 = line_start[last] - 1;         // span of the wave's lines, 16-byte aligned start
-    const bool staged = g1 - g0 <= kTextSpanMax;
-    if (staged) {
-        for (int64_t q = g0 + 16 * threadIdx.x; q < g1; q += 16 * kTextLinesPerWG)
-            *reinterpret_cast<u32x4*>(span + (q - g0)) = ldg<u32x4>(text + q);           // (the text buffer is padded by 64 bytes)
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(region + 64 * t + 16 * k) = w[k];
+    const uint64_t nl = text_eq_mask(w, '\n'), sp = text_eq_mask(w, sep), cm = text_eq_mask(w, comm);
+    const uint64_t nlm = nl & bits_from(kTextLead - 1 - 64 * t);       // newlines that start a line at or behind the tile's first byte
+    const uint64_t own = text_own_mask(nl, t, R, n);
+    __syncthreads();
+    if (cm) atomicOr(&s_flags, 1u);
+    if (own) atomicAdd(&s_nown, (unsigned)__popcll(own));
+    int nl_total;
+    const int nl_before = block_exclusive_scan(__popcll(nlm), wsum, &nl_total);      // (its barriers publish s_flags / s_nown)
+    const int nown = (int)s_nown;
+    // general path: a comment somewhere in the staged text, or the tile's last line does not end inside it
+    bool general = (s_flags & 1u) || (nown > 0 && nl_total < nown + 1);
+
+    if (!general) {
+        const uint8_t prevb = t ? region[64 * t - 1] : (uint8_t)'\n';
+        const uint64_t content = ~(nl | sp);
+        const uint64_t start = content & ~((content << 1) | ((prevb != sep && prevb != '\n') ? 1ull : 0ull));
+        // fields since the last newline: segmented sum, value = flag "a newline seen" << 31 | count
+        const int lastnl = nlm ? 63 - __builtin_clzll(nlm) : -1;
+        const uint32_t seg = nlm ? (0x80000000u | (uint32_t)__popcll(start & bits_from(lastnl + 1))) : (uint32_t)__popcll(start);
+        uint32_t incl = seg;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(incl, o);
+            if (lane_id() >= o) incl = (incl >> 31) ? incl : ((a & 0x80000000u) | ((a + incl) & 0x7fffffffu));
+        }
+        uint32_t excl = __shfl_up(incl, 1);
+        if (lane_id() == 0) excl = 0;
+        if (lane_id() == 63) wseg[wave_id()] = incl;
         __syncthreads();
-    }
-    if (!v) return;
-    const uint8_t* const tb = staged ? span - g0 : text;          // tb[p] is byte p of the text either way (flat addressing)
-    const int64_t a = line_start[i], b = line_start[i + 1] - 1;
-    int64_t e = a;
-    while (e < b && tb[e] != comm) ++e;                           // uncomment(), parse.go:43-63
-    int field = 0;
-    int64_t p = a;
-    while (p < e) {
-        while (p < e && tb[p] == sep) ++p;                        // fields(), parse.go:172-211
-        if (p >= e) break;
-        const int64_t t0 = p;
-        while (p < e && tb[p] != sep) ++p;
-        if (field <= cols.max_field && field < kTextMaxCols) {
-            const int sl = cols.slot[field];
-            if (sl >= 0x4000) {
-                int64_t x;
-                if (text_atoi(tb + t0, (int)(p - t0), &x)) cols.iout[sl - 0x4000][row] = x;
-                else text_error(st, i, kTextErrInt);
-            } else if (sl >= 0) {
-                double x;
-                const int rc = text_atof(tb + t0, (int)(p - t0), &x);
-                if (rc == 0) cols.fout[sl][row] = (float)x;                          // float32(x), parse.go:165
-                else if (rc == 1) {
-                    const unsigned k = atomicAdd(&st->n_slow, 1u);
-                    if (k < slow_cap) { TextSlow w = {row, t0, (int32_t)(p - t0), sl}; slow[k] = w; }
-                } else text_error(st, i, kTextErrFloat);
+        uint32_t pre = 0;
+        for (int k = 0; k < wave_id(); ++k) { const uint32_t b = wseg[k]; pre = (b >> 31) ? b : ((pre & 0x80000000u) | ((pre + b) & 0x7fffffffu)); }
+        const uint32_t carry = (excl >> 31) ? excl : ((pre & 0x80000000u) | ((pre + excl) & 0x7fffffffu));
+        const int carry_cnt = (int)(carry & 0x7fffffffu);
+        // the newlines of the chunk: which of them end an owned line that has fields (a kept line)
+        uint64_t validend = 0;
+        {
+            uint64_t m = nlm;
+            int prev = -1, cnt_in = carry_cnt, j = 0;
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const int cnt = cnt_in + __popcll(start & bits_below(b) & bits_from(prev + 1));
+                const int l = nl_before + j;                       // the line this newline ends was started by counted newline l - 1
+                if (l >= 1 && l <= nown && cnt > 0) {
+                    validend |= 1ull << b;
+                    if (cnt != cols.fields_expected) text_error(st, line_base + l - 1, kTextErrFields);     // parse.go:114-118
+                }
+                cnt_in = 0; prev = b; ++j;
             }
         }
-        ++field;
+        int vtotal;
+        const int vbase = block_exclusive_scan(__popcll(validend), wsum, &vtotal);
+        if (vtotal > kTextMaxRowOff) general = true;
+        else {
+            uint64_t m = start;
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t below = bits_below(b);
+                const uint64_t nlb = nlm & below;
+                const int l = nl_before + __popcll(nlb);           // started by counted newline l - 1
+                if (l < 1 || l > nown) continue;
+                const int fidx = nlb ? __popcll(start & below & bits_from(64 - __builtin_clzll(nlb))) : carry_cnt + __popcll(start & below);
+                if (fidx > cols.max_field) continue;
+                const int sl = s_slot[fidx];
+                if (sl < 0) continue;
+                const uint32_t rowoff = (uint32_t)(vbase + __popcll(validend & below));
+                const uint32_t code = sl >= 0x4000 ? 64u + (uint32_t)(sl - 0x4000) : (uint32_t)sl;
+                const unsigned k = atomicAdd(&s_nrec, 1u);
+                if (k < (unsigned)kTextRecCap) rec[k] = (uint32_t)(64 * t + b) | (rowoff << 14) | (code << 25);
+            }
+            __syncthreads();
+            if (s_nrec > (unsigned)kTextRecCap) general = true;
+        }
     }
-    if (field != cols.fields_expected) text_error(st, i, kTextErrFields);
+
+    if (!general) {
+        const unsigned nrec = s_nrec;
+        for (unsigned k = t; k < nrec; k += 256) {
+            const uint32_t r = rec[k];
+            const int pos = (int)(r & 0x3fffu);
+            const int64_t row = row_base + ((r >> 14) & 0x7ffu);
+            const uint32_t code = r >> 25;
+            const uint8_t* tok = region + pos;
+            int len = 0;
+            while (pos + len < kTextRegion && tok[len] != sep && tok[len] != '\n') ++len;
+            if (row >= capacity) { atomicOr(&st->flags, 1u); continue; }
+            int bad = 0;
+            if (code >= 64u) {
+                int64_t x;
+                if (text_atoi(tok, len, &x)) s_iout[code - 64u][row] = x;
+                else bad = kTextErrInt;
+            } else {
+                double x;
+                const int rc = text_atof(tok, len, &x);
+                if (rc == 0) s_fout[code][row] = (float)x;                                  // float32(x), parse.go:165
+                else if (rc == 1) {
+                    const unsigned q = atomicAdd(&st->n_slow, 1u);
+                    if (q < slow_cap) { TextSlow ws = {row, R + pos, (int32_t)len, (int32_t)code}; slow[q] = ws; }
+                } else bad = kTextErrFloat;
+            }
+            if (bad) {                                          // the line number is only needed here: the newlines in front of the field
+                int c = 0;
+                for (int q = kTextLead - 1; q < pos; ++q) c += region[q] == '\n';
+                text_error(st, line_base + c - 1, bad);
+            }
+        }
+        return;
+    }
+
+    // ---- general path: the lines behind the thread's owned newlines, one after the other, as the reference walks them ----
+    if (t == 0) atomicAdd(&st->tiles_general, 1u);
+    uint64_t vmask = 0;
+    {
+        uint64_t m = own;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            if (text_line_valid(text, R + 64 * t + b + 1, n, sep, comm)) vmask |= 1ull << b;
+        }
+    }
+    int vtot;
+    int64_t row = row_base + block_exclusive_scan(__popcll(vmask), wsum, &vtot);
+    while (vmask) {
+        const int b = __builtin_ctzll(vmask);
+        vmask &= vmask - 1;
+        const int64_t a = R + 64 * t + b + 1;
+        const int64_t line = line_base + nl_before + __popcll(nlm & bits_below(b));
+        int64_t e = a;
+        while (e < n && text[e] != '\n' && text[e] != comm) ++e;                        // uncomment(), parse.go:43-63
+        // the line through a pointer to its first byte: the staged copy if the whole line is in it, else the text itself
+        const uint8_t* const lb = e <= R + kTextRegion ? region + (a - R) : text + a;
+        const int64_t ll = e - a;
+        int field = 0;
+        int64_t p = 0;
+        while (p < ll) {
+            while (p < ll && lb[p] == sep) ++p;                                         // fields(), parse.go:172-211
+            if (p >= ll) break;
+            const int64_t t0 = p;
+            while (p < ll && lb[p] != sep) ++p;
+            if (field <= cols.max_field && field < kTextMaxCols) {
+                const int sl = s_slot[field];
+                if (sl >= 0) text_convert(lb + t0, (int)(p - t0), sl, row, line, a + t0, s_fout, s_iout, capacity, slow, slow_cap, st);
+            }
+            ++field;
+        }
+        if (field != cols.fields_expected) text_error(st, line, kTextErrFields);
+        ++row;
+    }
 }
 
-void launch_text_count(hipStream_t s, const uint8_t* text, int64_t n, uint32_t* tile_nl) {
+void launch_text_count(hipStream_t s, const uint8_t* text, int64_t n, uint8_t sep, uint8_t comm, int64_t* tile_cnt) {
     const int64_t tiles = (n + kTextTile - 1) / kTextTile;
-    hipLaunchKernelGGL(k_text_count, dim3((unsigned)tiles), dim3(256), 0, s, text, n, tile_nl);
+    hipLaunchKernelGGL(k_text_count, dim3((unsigned)tiles), dim3(256), 0, s, text, n, sep, comm, tile_cnt);
 }
-void launch_text_lines(hipStream_t s, const uint8_t* text, int64_t n, const int64_t* tile_base, int64_t* line_start) {
+void launch_text_scan(hipStream_t s, int64_t* tile_cnt, int64_t tiles, TextState* st) {
+    hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, s, tile_cnt, tiles, st);
+}
+void launch_text_parse(hipStream_t s, const uint8_t* text, int64_t n, uint8_t sep, uint8_t comm, const int64_t* tile_base, const TextCols& cols,
+                       int64_t capacity, TextSlow* slow, unsigned slow_cap, TextState* st) {
     const int64_t tiles = (n + kTextTile - 1) / kTextTile;
-    hipLaunchKernelGGL(k_text_lines, dim3((unsigned)tiles), dim3(256), 0, s, text, n, tile_base, line_start);
-}
-void launch_text_valid(hipStream_t s, const uint8_t* text, const int64_t* line_start, int64_t nlines, uint8_t sep, uint8_t comm,
-                       uint8_t* valid, uint32_t* tile_valid) {
-    hipLaunchKernelGGL(k_text_valid, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, s, text, line_start, nlines, sep, comm, valid, tile_valid);
-}
-void launch_text_parse(hipStream_t s, const uint8_t* text, const int64_t* line_start, int64_t nlines, uint8_t sep, uint8_t comm,
-                       const uint8_t* valid, const int64_t* tile_vbase, const TextCols& cols, TextSlow* slow, unsigned slow_cap, TextState* st) {
-    hipLaunchKernelGGL(k_text_parse, dim3((unsigned)((nlines + kTextLinesPerWG - 1) / kTextLinesPerWG)), dim3(kTextLinesPerWG), 0, s, text,
-                       line_start, nlines, sep, comm, valid, tile_vbase, cols, slow, slow_cap, st);
+    hipLaunchKernelGGL(k_text_parse, dim3((unsigned)tiles), dim3(256), 0, s, text, n, sep, comm, tile_base, cols, capacity, slow, slow_cap, st);
 }

@@ -109,6 +109,67 @@ def test_random_catalogues(mnw, oracle, torch_mod):
             _parse(mnw, torch_mod, c, b"1,2,3\n4,5,6\n", ord(","), ord("#"), [1], [0])
 
 
+def test_tile_geometry(mnw, oracle, torch_mod):
+    """lines of every awkward length against the 12,288-byte tiles and the 16,384 bytes a workgroup stages: newlines on
+    and around tile boundaries, lines longer than the staged overhang (4,080 bytes), longer than a tile, longer than
+    the staged text; blank lines; with and without a final newline; the fast path must have taken the plain ones"""
+    rng = np.random.default_rng(11)
+    with mnw.Context(0) as c:
+        for L in [1, 2, 3, 5, 11, 12, 47, 48, 63, 64, 65, 127, 128, 1023, 4079, 4080, 4081, 4095, 4096, 4097, 12287, 12288, 12289, 16384, 40001]:
+            nlines = max(3 * 12288 // L + 7, 9)
+            nlines = min(nlines, 20000)
+            out = []
+            for i in range(nlines):
+                if L < 4:
+                    tok = str(i % 10)
+                    ln = " " * (L - 1 - len(tok)) + tok if L - 1 >= len(tok) else ""
+                else:
+                    a, b = str(i % 7), "%.3g" % rng.normal(0, 50)
+                    body = a + " " + b
+                    ln = (body + " " * (L - 1 - len(body))) if L - 1 >= len(body) else a + " 1"
+                    if i % 3 == 0 and L - 1 > len(body) + 2:
+                        pad = L - 1 - len(body)
+                        ln = " " * (pad // 2) + a + " " * (pad - pad // 2 - 0) + b
+                        ln = ln[:L - 1] if len(ln) > L - 1 else ln + " " * (L - 1 - len(ln))
+                out.append(ln)
+            data = "\n".join(out).encode() + (b"\n" if L % 2 else b"")
+            if L < 4:
+                n = _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [], [0])
+            else:
+                n = _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0])
+            if n == 0:
+                continue
+            lines, kept, general = c.text_stats()
+            assert lines == data.count(b"\n") + 1 and kept == n
+            if 11 <= L <= 4080:
+                assert general == 0, (L, general)
+            if L > 16368:                          # cannot end inside the staged text wherever it starts
+                assert general > 0
+        # random line lengths, blank lines and separator-only lines in between
+        for trial in range(3):
+            out = []
+            for i in range(4000):
+                r = rng.random()
+                if r < 0.05:
+                    out.append("")
+                elif r < 0.1:
+                    out.append(" " * int(rng.integers(1, 300)))
+                else:
+                    pad = int(rng.integers(1, 40)) if r < 0.95 else int(rng.integers(1, 6000))
+                    out.append(" " * int(rng.integers(0, 4)) + str(int(rng.integers(-99, 10**9))) + " " * pad + "%.4f" % rng.uniform(0, 250) + " " * int(rng.integers(0, 3)))
+            data = "\n".join(out).encode()
+            _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0])
+        # comments in the middle of the data: those tiles take the general path, the rest does not
+        out = ["%d %.3f" % (i, i * 0.25) + (" # note" if i == 5000 else "") for i in range(20000)]
+        data = ("# header\n" + "\n".join(out) + "\n").encode()
+        n = _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0])
+        lines, kept, general = c.text_stats()
+        assert n == 20000 and 1 <= general <= 4 and lines == 20002
+        # capacity: one row short
+        with pytest.raises(mnw.MnwError):
+            _parse(mnw, torch_mod, c, data, ord(" "), ord("#"), [1], [0], cap=19999)
+
+
 def test_hard_float_literals(mnw, oracle, torch_mod):
     """literals outside the device's exact fast path (more than 15-19 digits, exponents beyond 10^+-22, subnormals,
     halfway cases of the float64 and of the float32 rounding, inf/nan spellings): converted on the host with strtod"""
