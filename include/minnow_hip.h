@@ -242,6 +242,28 @@ int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t se
  * one-thread-per-field path. */
 int mnw_text_stats(mnw_ctx *ctx, int64_t out[3]);
 
+/* ---- device memory for callers without a HIP binding (a cgo shim, include/minh.hpp) -------------------------
+ * Plain hipMalloc / hipFree / hipMemcpy on the context's device; the copies are synchronous (they return when the
+ * bytes have arrived) and ordered behind the work already enqueued on the context's own stream. */
+int mnw_dev_alloc(mnw_ctx *ctx, int64_t nbytes, void **dev_ptr);
+int mnw_dev_free(mnw_ctx *ctx, void *dev_ptr);
+int mnw_copy_to_device(mnw_ctx *ctx, void *dev_dst, const void *host_src, int64_t nbytes);
+int mnw_copy_to_host(mnw_ctx *ctx, void *host_dst, const void *dev_src, int64_t nbytes);
+
+/* ---- GenericCut of the reference's text_to_minh (scripts/text_to_minh.go:271-312) ----------------------------
+ * Keeps, in order and in every column, the rows i with mass[i] > cutoff (ok[i] = m[i] > cutoff; filterFloat32 /
+ * filterInt64).  All pointers are DEVICE pointers; mass may be the src of one of the columns; dst != src (the device
+ * compacts out of place); elem_bytes is 4 ([]float32) or 8 ([]int64).  *n_kept = rows kept (GenericCut's return
+ * value); synchronous with respect to it. */
+typedef struct mnw_cut_col {
+    const void *src;
+    void *dst;
+    int32_t elem_bytes;
+    int32_t reserved;
+} mnw_cut_col;
+int mnw_generic_cut(mnw_ctx *ctx, mnw_stream_t stream, const float *mass, float cutoff, int64_t n,
+                    const mnw_cut_col *cols, int ncols, int64_t *n_kept);
+
 /* Raw bit.Array pack / unpack on device buffers (bit.go:84-134, 29-82); enqueue only.
  * out of pack must be 16-byte aligned. */
 int mnw_pack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint64_t *x, int64_t n, int bits,
@@ -271,7 +293,8 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_MINH_UNLOG  15  /* minh reader: 10^x */
 #define MNW_K_TEXT_LINES  16  /* text ingest: lines and kept lines per tile + prefix (k_text_count, k_text_scan) */
 #define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers (k_text_parse) */
-#define MNW_K_COUNT       18
+#define MNW_K_CUT         18  /* GenericCut: count + prefix, scatter */
+#define MNW_K_COUNT       19
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;

@@ -10,7 +10,7 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 18
+K_COUNT = 19
 
 
 class MnwError(RuntimeError):
@@ -41,6 +41,10 @@ class BlockMetaC(C.Structure):
 class MinhColC(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int64), ("low", C.c_float), ("high", C.c_float),
                 ("log", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CutColC(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("elem_bytes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class KernelTimeC(C.Structure):
@@ -91,6 +95,11 @@ SIGNATURES = {
     "mnw_minh_selftest": (_int, [_p, _int, _u64, _u64, C.POINTER(_u64)]),
     "mnw_text_parse": (_int, [_p, _p, _i64, C.c_uint8, C.c_uint8, C.POINTER(C.c_int32), _int, C.POINTER(_p),
                               C.POINTER(C.c_int32), _int, C.POINTER(_p), _i64, C.POINTER(_i64)]),
+    "mnw_dev_alloc": (_int, [_p, _i64, C.POINTER(_p)]),
+    "mnw_dev_free": (_int, [_p, _p]),
+    "mnw_copy_to_device": (_int, [_p, _p, _p, _i64]),
+    "mnw_copy_to_host": (_int, [_p, _p, _p, _i64]),
+    "mnw_generic_cut": (_int, [_p, _p, _p, C.c_float, _i64, C.POINTER(CutColC), _int, C.POINTER(_i64)]),
     "mnw_text_stats": (_int, [_p, C.POINTER(_i64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),

@@ -7,7 +7,7 @@ import ctypes as C
 from dataclasses import dataclass
 
 from . import _lib
-from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MinhColC, MnwError
+from ._lib import BlockMetaC, DecJobC, EncJobC, KernelTimeC, MinhColC, CutColC, MnwError
 
 INT_GROUP = 10     # go/group.go:22
 FLOAT_GROUP = 11   # go/group.go:23
@@ -246,6 +246,13 @@ class Context:
         self._check(self._L.mnw_text_parse(self._h, buf, len(data), sep, comment, fc, len(float_cols), fo, ic, len(int_cols), io,
                                            capacity_rows, C.byref(n)))
         return n.value
+
+    def generic_cut(self, mass_ptr, cutoff, n, cols, stream=None):
+        """GenericCut (scripts/text_to_minh.go:271-312): cols = [(src_ptr, dst_ptr, elem_bytes)] device columns -> rows kept"""
+        arr = (CutColC * max(len(cols), 1))(*[CutColC(s, d, e, 0) for s, d, e in cols])
+        kept = C.c_int64(0)
+        self._check(self._L.mnw_generic_cut(self._h, stream, mass_ptr, cutoff, n, arr, len(cols), C.byref(kept)))
+        return kept.value
 
     def text_stats(self):
         """of the last text_parse: (lines, lines kept, tiles on the general path)"""

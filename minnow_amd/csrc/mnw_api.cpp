@@ -50,6 +50,10 @@ struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned in
 void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, int64_t*);
 void launch_text_scan(hipStream_t, int64_t*, int64_t, TextState*);
 void launch_text_parse(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, const int64_t*, const TextCols&, int64_t, TextSlow*, unsigned, TextState*);
+constexpr int kCutTile = 2048, kCutMaxCols = 64;
+struct CutCols { const void* src[kCutMaxCols]; void* dst[kCutMaxCols]; uint8_t esz[kCutMaxCols]; int32_t n; };
+void launch_cut_count(hipStream_t, const float*, float, int64_t, int64_t*);
+void launch_cut_scatter(hipStream_t, const float*, float, int64_t, const int64_t*, const CutCols&);
 void launch_quantize_i64(hipStream_t, int, const float*, int64_t, float, float, int64_t*);
 void launch_periodic_min_seq(hipStream_t, const int64_t*, int64_t, int64_t, int64_t, int64_t*);
 void launch_bound_i64(hipStream_t, int, int64_t*, int64_t, int64_t, int64_t);
@@ -701,6 +705,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_MINH_UNLOG: return "k_minh_unlog";
         case MNW_K_TEXT_LINES: return "k_text_count+k_text_scan";
         case MNW_K_TEXT_PARSE: return "k_text_parse";
+        case MNW_K_CUT: return "k_cut_count+scan / k_cut_scatter";
         default: return "";
     }
 }
@@ -1420,6 +1425,72 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             HIPCHK(c, hipMemcpy(float_out[w.slot] + w.row, &f, sizeof f, hipMemcpyHostToDevice));
         }
     }
+    return MNW_OK;
+}
+
+// ---- device memory for callers without a HIP binding ---------------------------------------------------
+int mnw_dev_alloc(mnw_ctx* c, int64_t nbytes, void** p) {
+    if (!c || !p || nbytes < 0) return fail(c, MNW_E_ARG, "dev_alloc: bad arguments");
+    *p = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (hipMalloc(p, (size_t)(nbytes > 0 ? nbytes : 1)) != hipSuccess) { (void)hipGetLastError(); return fail(c, MNW_E_NOMEM, "dev_alloc: out of device memory"); }
+    return MNW_OK;
+}
+int mnw_dev_free(mnw_ctx* c, void* p) {
+    if (!c) return MNW_E_ARG;
+    if (p) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipFree(p)); }
+    return MNW_OK;
+}
+int mnw_copy_to_device(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
+    if (!c || nbytes < 0 || (nbytes > 0 && (!dst || !src))) return fail(c, MNW_E_ARG, "copy_to_device: bad arguments");
+    if (nbytes == 0) return MNW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+int mnw_copy_to_host(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
+    if (!c || nbytes < 0 || (nbytes > 0 && (!dst || !src))) return fail(c, MNW_E_ARG, "copy_to_host: bad arguments");
+    if (nbytes == 0) return MNW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+
+// ---- GenericCut (scripts/text_to_minh.go:271-312) ------------------------------------------------------
+int mnw_generic_cut(mnw_ctx* c, mnw_stream_t stream, const float* mass, float cutoff, int64_t n, const mnw_cut_col* cols, int ncols,
+                    int64_t* n_kept) {
+    if (!c || !n_kept || n < 0 || ncols < 0 || (ncols > 0 && !cols) || (n > 0 && !mass)) return fail(c, MNW_E_ARG, "cut: bad arguments");
+    *n_kept = 0;
+    if (n == 0) return MNW_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    for (int k = 0; k < ncols; ++k) {
+        if (!cols[k].src || !cols[k].dst || (cols[k].elem_bytes != 4 && cols[k].elem_bytes != 8)) return fail(c, MNW_E_ARG, "cut: null column or element size not 4 / 8");
+        if (((uintptr_t)cols[k].src | (uintptr_t)cols[k].dst) & (uintptr_t)(cols[k].elem_bytes - 1)) return fail(c, MNW_E_ARG, "cut: misaligned column");
+        if (cols[k].src == cols[k].dst) return fail(c, MNW_E_ARG, "cut: a column cannot be filtered in place");
+    }
+    const int64_t tiles = (n + mnw::kCutTile - 1) / mnw::kCutTile;
+    int rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)(tiles + 1) * 8 + 16);
+    if (rc) return rc;
+    {
+        ScopedTimer t(c, s, MNW_K_CUT);
+        mnw::launch_cut_count(s, mass, cutoff, n, (int64_t*)c->d_tile);
+    }
+    for (int k0 = 0; k0 < ncols; k0 += mnw::kCutMaxCols) {
+        mnw::CutCols cc;
+        memset(&cc, 0, sizeof cc);
+        cc.n = ncols - k0 < mnw::kCutMaxCols ? ncols - k0 : mnw::kCutMaxCols;
+        for (int k = 0; k < cc.n; ++k) { cc.src[k] = cols[k0 + k].src; cc.dst[k] = cols[k0 + k].dst; cc.esz[k] = (uint8_t)cols[k0 + k].elem_bytes; }
+        ScopedTimer t(c, s, MNW_K_CUT);
+        mnw::launch_cut_scatter(s, mass, cutoff, n, (const int64_t*)c->d_tile, cc);
+    }
+    HIPCHK(c, hipGetLastError());
+    int64_t kept = 0;
+    HIPCHK(c, hipMemcpyAsync(&kept, (const int64_t*)c->d_tile + tiles, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_kept = kept;
     return MNW_OK;
 }
 

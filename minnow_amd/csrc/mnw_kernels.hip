@@ -1824,6 +1824,7 @@ __global__ __launch_bounds__(kThreads) void k_prepare(const uint32_t* __restrict
 #include "mnw_subcell.hip"
 #include "mnw_minh.hip"
 #include "mnw_text.hip"
+#include "mnw_cut.hip"
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from mnw_api.cpp)

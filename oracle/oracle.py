@@ -390,3 +390,12 @@ def text_block_parse(data, sep, comm, float_cols, int_cols):
                 raise ValueError("strconv.Atoi: value out of range")
             iout[k][i] = v
     return fout, iout
+
+
+def generic_cut(cutoff, mass, cols):
+    """GenericCut of scripts/text_to_minh.go:271-312: ok[i] = m[i] > cutoff (float32 compare, false for NaN), every
+    column keeps its ok rows in order.  Returns (n kept, filtered columns)."""
+    m = np.asarray(mass, dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        ok = m > np.float32(cutoff)
+    return int(ok.sum()), [np.asarray(x)[ok] for x in cols]
