@@ -180,6 +180,9 @@ struct group {
     virtual void writeTail(std::FILE* f) = 0;
     virtual int64_t blockOffset(int b) const = 0;
     virtual void readData(std::FILE* f, int b, void* out, size_t n) = 0;
+    // a block the caller has already encoded on the device (batched mnw_encode_blocks): the stream and what
+    // intGroup.writeData would have appended to g.mins / g.bits (group.go:251-254)
+    virtual void writeEncoded(std::FILE*, const uint8_t*, size_t, int64_t, int64_t) { throw Error("this group type is not a codec group"); }
 };
 
 // go/group.go:109-163: raw copy, no codec involved
@@ -265,6 +268,13 @@ struct intGroup : group {
         bits.push_back(b);
         idx.addBlock(bit::ArrayBytes((int)b, (int)N));
     }
+    void writeEncoded(std::FILE* f, const uint8_t* stream, size_t nbytes, int64_t mn, int64_t b) override {
+        if ((int64_t)nbytes != (b == 0 ? 0 : bit::ArrayBytes((int)b, (int)N))) throw Error("encoded block has the wrong length", MNW_E_BUFLEN);
+        detail::fwrite_all(f, stream, nbytes);
+        mins.push_back(mn);
+        bits.push_back(b);
+        idx.addBlock(bit::ArrayBytes((int)b, (int)N));
+    }
     // intGroup.readData, group.go:257-263
     void readData(std::FILE* f, int b, void* out, size_t n) override {
         const size_t bIdx = (size_t)(b - (int)idx.startBlock);
@@ -313,6 +323,7 @@ struct floatGroup : group {
         ig->bits.push_back(b);
         ig->idx.addBlock(bit::ArrayBytes((int)b, (int)ig->N));
     }
+    void writeEncoded(std::FILE* f, const uint8_t* stream, size_t nbytes, int64_t mn, int64_t b) override { ig->writeEncoded(f, stream, nbytes, mn, b); }
     // floatGroup.readData, group.go:299-310
     void readData(std::FILE* f, int b, void* out, size_t n) override {
         const size_t bIdx = (size_t)(b - (int)ig->idx.startBlock);
@@ -401,6 +412,24 @@ class Writer {
         return blocks_ - 1;
     }
     template <typename T> int Data(const std::vector<T>& x) { return Data(x.data(), x.size()); }
+    // Data for a block of the current IntGroup / FloatGroup that was encoded on the device by the caller (one batched
+    // mnw_encode_blocks call for many blocks): same bookkeeping as Data, the stream is written as it is
+    int DataEncoded(const uint8_t* stream, size_t nbytes, int64_t min, int64_t bits) {
+        if (currGroup_ == -1) throw Error("Data written to minnow.Writer without assigning Group first.");
+        writers_.back()->writeEncoded(f_, stream, nbytes, min, bits);
+        ++groupBlocks_.back();
+        ++blocks_;
+        return blocks_ - 1;
+    }
+    // Data for a block of the current fixed-size group given as raw bytes (n elements of the group's type)
+    int DataRaw(const void* x, size_t n) {
+        if (currGroup_ == -1) throw Error("Data written to minnow.Writer without assigning Group first.");
+        if (!(currGroup_ >= Int64Group && currGroup_ <= Float32Group)) throw Error("DataRaw needs a fixed-size group");
+        writers_.back()->writeData(f_, x, n);
+        ++groupBlocks_.back();
+        ++blocks_;
+        return blocks_ - 1;
+    }
 
     // Close, writer.go:107-141
     void Close() {
@@ -486,6 +515,10 @@ class Reader {
     int DataLen(int b) const { return readers_[blockIndex_.at((size_t)b)]->length(b); }      // reader.go:135-137
     void Close() { if (f_) { std::fclose(f_); f_ = nullptr; } }                              // reader.go:140-142
     group* Group(int i) { return readers_.at((size_t)i).get(); }
+    // for callers that decode blocks on the device themselves: the group of block b, where its bytes start in the file
+    int GroupOf(int b) const { return blockIndex_.at((size_t)b); }
+    int64_t BlockFileOffset(int b) const { const int i = GroupOf(b); return groupOffsets_[i] + readers_[i]->blockOffset(b); }
+    std::FILE* File() { return f_; }
 
    private:
     std::FILE* f_ = nullptr;

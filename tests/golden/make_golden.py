@@ -233,6 +233,40 @@ def main():
     write_file("q_float_record.minw", q_float_record)
     small["minw_files"] = files
 
+    # ---- 8. a whole minh file written by the reference python minh.Writer (python/minh.py:36-98) -----------
+    # The columns of TestReaderWriter (go/minh/minh_test.go:21-27) with two changes that keep the Python and the Go
+    # derivations identical bit for bit: the logarithmic column's Dx is 0.125 (Python's float64 pixel count for
+    # (10, 14, 0.01) is 401, Go's float32 one 400 -- SURVEY.md 8c) and its values keep clear of pixel edges (Python takes
+    # the logarithm in float32, Go in float64).  tests/cpp/test_minh_host.cpp writes the same file and compares bytes.
+    import minh  # reference python/minh.py
+    mcols = [minh.Column(minnow.int64_group), minh.Column(minnow.float32_group), minh.Column(minnow.int_group),
+             minh.Column(minnow.float_group, 0, 100, 200, 1), minh.Column(minnow.float_group, 1, 10, 14, 0.125)]
+    for c in mcols[3:]:
+        assert go_pixels(c.low, c.high, c.dx) == int(np.ceil((c.high - c.low) / c.dx))
+    mblocks = [
+        [np.array([100, 200, 300, 400, 500], dtype=np.int64), np.array([150, 250, 350, 450, 550], dtype=np.float32),
+         np.array([-30, -35, -25, -10, -20], dtype=np.int64), np.array([100, 200, 125, 150, 100], dtype=np.float32),
+         np.array([1e10, 2e11, 2e11, 1e14, 3e13], dtype=np.float32)],
+        [np.array([125, 225, 325], dtype=np.int64), np.array([1750, 2750, 3750], dtype=np.float32),
+         np.array([1000, 1000, 1000], dtype=np.int64), np.array([100, 100, 100], dtype=np.float32),
+         np.array([1e14, 1e14, 1e14], dtype=np.float32)],
+    ]
+    for blk in mblocks:                                       # the two logarithms agree on the pixel of every value
+        x = blk[4]
+        py = np.log10(x.copy())
+        go = np.log10(x.astype(np.float64)).astype(np.float32)
+        q = lambda v: np.floor((np.clip(v, 10, np.nextafter(np.float32(14), np.float32(-np.inf))) - 10) / 0.125)
+        assert np.array_equal(q(py), q(go))
+    mtext = "Cats are the best. Don't we love them?!@#$%^&*(),....[]{};':\"|\\/-=_+`~meow meow meow"
+    mpath = "/tmp/test_files/reader_writer_golden.minh"
+    w = minh.create(mpath)
+    w.header(["int64", "float32", "int", "float", "log"], mtext, mcols)
+    w.geometry(100.0, 10.0, 4)
+    for blk in mblocks:
+        w.block(blk)
+    w.close()
+    small["minh_files"] = {"reader_writer_golden.minh": open(mpath, "rb").read().hex()}
+
     np.savez_compressed(os.path.join(HERE, "pack_kat.npz"), **arrays)
     with open(os.path.join(HERE, "golden_small.json"), "w") as f:
         json.dump(small, f, separators=(",", ":"))

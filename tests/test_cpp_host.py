@@ -13,20 +13,27 @@ SRC = os.path.join(ROOT, "tests", "cpp", "test_minnow_host.cpp")
 BIN = os.path.join(ROOT, "tests", "cpp", "test_minnow_host")
 
 
-def _build():
+MINH_SRC = os.path.join(ROOT, "tests", "cpp", "test_minh_host.cpp")
+MINH_BIN = os.path.join(ROOT, "tests", "cpp", "test_minh_host")
+
+
+def _build(src=SRC, exe=BIN):
     from minnow_amd import build as b
     b.build()
     lib_dir = os.path.join(ROOT, "minnow_amd")
-    if (not os.path.exists(BIN)) or os.path.getmtime(BIN) < max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(ROOT, "include", "minnow.hpp"))):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", BIN,
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("minnow.hpp", "minh.hpp", "minnow_hip.h")] + [b.LIB]
+    if (not os.path.exists(exe)) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L", lib_dir, "-lminnow_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
-    return BIN
+    return exe
 
 
 def test_host_header_compiles_and_links():
     """No GPU needed: the header is valid C++17 and every symbol it uses is exported by the library."""
     _build()
     assert os.path.exists(BIN)
+    _build(MINH_SRC, MINH_BIN)
+    assert os.path.exists(MINH_BIN)
 
 
 @pytest.mark.gpu
@@ -42,3 +49,20 @@ def test_cpp_host_tests_on_gpu(tmp_path):
     r = subprocess.run([exe, str(scratch), str(gold)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok: 7 host tests" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_minh_host_tests_on_gpu(tmp_path):
+    """include/minh.hpp: the reference's TestReaderWriter (go/minh/minh_test.go:10-117), a whole minh file byte for byte
+    against the reference Python minh.Writer's, device-array forms against host-array forms, the panics"""
+    exe = _build(MINH_SRC, MINH_BIN)
+    small = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_small.json")))
+    gold = tmp_path / "golden"
+    gold.mkdir()
+    for name, hx in small["minh_files"].items():
+        (gold / name).write_bytes(bytes.fromhex(hx))
+    scratch = tmp_path / "test_files"
+    scratch.mkdir()
+    r = subprocess.run([exe, str(scratch), str(gold)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: 4 minh host tests" in r.stdout
