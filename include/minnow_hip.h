@@ -237,6 +237,13 @@ int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t se
                    const int32_t *float_cols, int n_float, float *const *float_out,
                    const int32_t *int_cols, int n_int, int64_t *const *int_out,
                    int64_t capacity_rows, int64_t *n_rows);
+/* The first half of mnw_text_parse on its own: copies the block to the device, counts its lines and the lines that will
+ * be kept (what the reference knows after split / uncomment / trim and sizes its outputs with: expandGeneric(out[i],
+ * len(lines)), text.go:192), and leaves the copy and the counts on the device.  The mnw_text_parse call that directly
+ * follows with the same text, nbytes, sep and comment (the buffer unchanged) skips the upload and the counting.
+ * Synchronous. */
+int mnw_text_rows(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t sep, uint8_t comment,
+                  int64_t *n_lines, int64_t *n_rows);
 /* Of the last mnw_text_parse: out[0] = lines (split()'s tokens), out[1] = lines kept, out[2] = 12 KB tiles of text that
  * took the general one-thread-per-line path (a comment character or an overlong line in reach) instead of the
  * one-thread-per-field path. */

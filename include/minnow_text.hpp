@@ -1,0 +1,236 @@
+// Text catalogue reader (go/text/text.go, go/text/rockstar.go) over the C ABI: the reference's Reader / Rockstar with their
+// names and panics (as exceptions).  File handling -- blocks of at most MaxBlockSize bytes cut at a newline found in the
+// last MaxItemSize bytes (findBlocks / nextBlock, text.go:82-131), the header lines (133-163) -- stays on the host as in
+// the reference; Reader.Block hands the block's bytes to the GPU (mnw_text_rows + mnw_text_parse) instead of splitting
+// and converting them on SetThreads(n) goroutines, and returns DEVICE columns, ready for mnw_generic_cut and
+// minh::Writer::BlockDevice.
+//
+// Header-only, C++17, needs only the C ABI (include/minnow_hip.h).
+#pragma once
+
+#include <algorithm>
+#include <cctype>
+
+#include "minnow.hpp"
+
+namespace text {
+
+using minnow::Error;
+
+// text.go:27-39
+struct ReaderConfig {
+    uint8_t Separator = ' ';
+    uint8_t Comment = '#';
+    int64_t MaxBlockSize = 5ll * (1ll << 30);
+    int64_t MaxItemSize = 100ll * (1ll << 10);
+};
+
+// the columns of one block on the device: what Block leaves in its out []interface{} of []int64 / []float32.  Owned by the
+// Reader and reused by the next Block call (the reference reuses its buffers the same way, expandGeneric, text.go:192)
+struct BlockColumns {
+    int64_t rows = 0;
+    std::vector<void*> ptr;          // ptr[i]: device int64[rows] or float32[rows] for names[i]
+};
+
+class Reader {
+   public:
+    // Open / openFromReader, text.go:42-67
+    explicit Reader(const std::string& fname, ReaderConfig config = ReaderConfig()) : config_(config) {
+        if (config_.MaxBlockSize / 2 < config_.MaxItemSize)
+            throw Error("config.MaxBlockSize = " + std::to_string(config_.MaxBlockSize) + ", but config.MaxLineSize = " + std::to_string(config_.MaxItemSize));
+        f_ = std::fopen(fname.c_str(), "rb");
+        if (!f_) throw Error("open " + fname + ": no such file or directory");
+        std::fseek(f_, 0, SEEK_END);
+        size_ = (int64_t)std::ftell(f_);
+        findBlocks();
+    }
+    ~Reader() {
+        Close();
+        mnw_ctx* ctx = minnow::detail::ctx();
+        for (void* p : dev_) if (p) mnw_dev_free(ctx, p);
+    }
+    Reader(const Reader&) = delete;
+    Reader& operator=(const Reader&) = delete;
+
+    // LineHeader, text.go:133-139: the first `lines` lines of the file
+    std::string LineHeader(int lines) {
+        std::vector<std::string> hd;
+        headerLines(hd);
+        if ((int)hd.size() <= lines) throw Error("config.MaxItemSize too small.");
+        return join(hd, (size_t)lines);
+    }
+    // CommentHeader, text.go:141-147.  As in the reference the number of header lines is the number of comment
+    // CHARACTERS in the first MaxItemSize bytes (split() counts bytes, parse.go:16-21): one per line in a Rockstar header.
+    std::string CommentHeader() {
+        std::vector<std::string> hd;
+        const int nComm = headerLines(hd);
+        if ((int)hd.size() == nComm) throw Error("config.MaxItemSize too small.");
+        if (nComm > (int)hd.size()) throw Error("slice bounds out of range");      // the reference's runtime panic
+        return join(hd, (size_t)nComm);
+    }
+
+    void SetNames(const std::vector<std::string>& names) { names_ = names; haveNames_ = true; }     // text.go:165-166
+    int Blocks() const { return (int)blockStarts_.size(); }                                         // text.go:168-169
+    int64_t BlockSize(int b) const { return blockSizes_.at((size_t)b); }
+    void SetThreads(int) {}                                                                          // text.go:174: the device parses
+    void Close() { if (f_) { std::fclose(f_); f_ = nullptr; } }                                     // text.go:171-172
+
+    // Block, text.go:176-200: the columns `names` of block b; isInt[i] says whether names[i] is read as []int64
+    // (strconv.Atoi) or as []float32 (float32(strconv.ParseFloat(s, 64)))
+    BlockColumns Block(int b, const std::vector<std::string>& names, const std::vector<bool>& isInt) {
+        if (!haveNames_) throw Error("Must call text.Reader.SetNames() before text.Reader.Blocks()");
+        if (names.size() != isInt.size()) throw Error("one type per name");
+        if (b < 0 || b >= Blocks()) throw Error("block index out of range");
+        mnw_ctx* ctx = minnow::detail::ctx();
+        buf_.resize((size_t)blockSizes_[(size_t)b]);
+        std::fseek(f_, (long)blockStarts_[(size_t)b], SEEK_SET);
+        minnow::detail::fread_all(f_, buf_.data(), buf_.size());
+        int64_t lines = 0, rows = 0;
+        minnow::detail::check(mnw_text_rows(ctx, buf_.data(), (int64_t)buf_.size(), config_.Separator, config_.Comment, &lines, &rows));
+        // splitByType, text.go:202-221
+        std::vector<int32_t> fIdx, iIdx;
+        std::vector<size_t> fAt, iAt;
+        for (size_t i = 0; i < names.size(); ++i) {
+            const int idx = nameIndex(names[i]);
+            if (isInt[i]) { iIdx.push_back(idx); iAt.push_back(i); } else { fIdx.push_back(idx); fAt.push_back(i); }
+        }
+        // expandGeneric, text.go:192: every output gets len(lines) elements
+        if (dev_.size() < names.size()) { dev_.resize(names.size(), nullptr); cap_.resize(names.size(), 0); }
+        BlockColumns out;
+        out.rows = rows;
+        out.ptr.resize(names.size());
+        for (size_t i = 0; i < names.size(); ++i) {
+            const size_t need = (size_t)rows * (isInt[i] ? 8 : 4) + 16;
+            if (cap_[i] < need) {
+                if (dev_[i]) minnow::detail::check(mnw_dev_free(ctx, dev_[i]));
+                dev_[i] = nullptr; cap_[i] = 0;
+                minnow::detail::check(mnw_dev_alloc(ctx, (int64_t)(need + need / 4), &dev_[i]));
+                cap_[i] = need + need / 4;
+            }
+            out.ptr[i] = dev_[i];
+        }
+        // at most 48 columns of each type per call of the C ABI
+        size_t f0 = 0, i0 = 0;
+        do {
+            const size_t nf = std::min<size_t>(48, fIdx.size() - f0), ni = std::min<size_t>(48, iIdx.size() - i0);
+            std::vector<float*> fo(nf);
+            std::vector<int64_t*> io(ni);
+            for (size_t k = 0; k < nf; ++k) fo[k] = static_cast<float*>(out.ptr[fAt[f0 + k]]);
+            for (size_t k = 0; k < ni; ++k) io[k] = static_cast<int64_t*>(out.ptr[iAt[i0 + k]]);
+            int64_t n = 0;
+            minnow::detail::check(mnw_text_parse(ctx, buf_.data(), (int64_t)buf_.size(), config_.Separator, config_.Comment,
+                                                 fIdx.data() + f0, (int)nf, fo.data(), iIdx.data() + i0, (int)ni, io.data(), rows, &n));
+            f0 += nf; i0 += ni;
+        } while (f0 < fIdx.size() || i0 < iIdx.size());
+        return out;
+    }
+
+   private:
+    // findBlocks / nextBlock, text.go:82-131
+    void findBlocks() {
+        int64_t curr = 0;
+        std::vector<uint8_t> buf;
+        for (;;) {
+            blockStarts_.push_back(curr);
+            if (curr + config_.MaxBlockSize >= size_) break;                       // no more blocks in the file
+            const int64_t searchStart = config_.MaxBlockSize - config_.MaxItemSize + curr;
+            buf.resize((size_t)config_.MaxItemSize);
+            std::fseek(f_, (long)searchStart, SEEK_SET);
+            minnow::detail::fread_all(f_, buf.data(), buf.size());
+            const auto it = std::find(buf.begin(), buf.end(), (uint8_t)'\n');
+            if (it == buf.end()) throw Error("config.MaxItemSize too small.");
+            curr = searchStart + (it - buf.begin()) + 1;
+        }
+        blockSizes_.resize(blockStarts_.size());
+        for (size_t i = 0; i + 1 < blockStarts_.size(); ++i) blockSizes_[i] = blockStarts_[i + 1] - blockStarts_[i];
+        blockSizes_.back() = size_ - blockStarts_.back();
+    }
+
+    // headerLines, text.go:149-163: the lines of the first MaxItemSize bytes and the number of comment characters in them
+    int headerLines(std::vector<std::string>& lines) {
+        const size_t n = (size_t)std::min(size_, config_.MaxItemSize);
+        std::string buf(n, '\0');
+        std::fseek(f_, 0, SEEK_SET);
+        minnow::detail::fread_all(f_, &buf[0], n);
+        int nComm = 0;
+        size_t a = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if ((uint8_t)buf[i] == config_.Comment) ++nComm;
+            if (buf[i] == '\n') { lines.push_back(buf.substr(a, i - a)); a = i + 1; }
+        }
+        lines.push_back(buf.substr(a));
+        return nComm;
+    }
+    static std::string join(const std::vector<std::string>& l, size_t n) {
+        std::string s;
+        for (size_t i = 0; i < n; ++i) { if (i) s += "\n"; s += l[i]; }
+        return s;
+    }
+    int nameIndex(const std::string& name) const {                                  // text.go:223-231
+        auto lower = [](std::string s) { for (char& c : s) c = (char)std::tolower((unsigned char)c); return s; };
+        const std::string want = lower(name);
+        for (size_t i = 0; i < names_.size(); ++i) if (lower(names_[i]) == want) return (int)i;
+        throw Error("Name '" + name + "' doesn't match to any columns.");
+    }
+
+    ReaderConfig config_;
+    std::FILE* f_ = nullptr;
+    int64_t size_ = 0;
+    std::vector<int64_t> blockStarts_, blockSizes_;
+    std::vector<std::string> names_;
+    bool haveNames_ = false;
+    std::vector<uint8_t> buf_;
+    std::vector<void*> dev_;
+    std::vector<size_t> cap_;
+};
+inline std::unique_ptr<Reader> Open(const std::string& fname, ReaderConfig config = ReaderConfig()) { return std::make_unique<Reader>(fname, config); }
+
+// go/text/rockstar.go
+class Rockstar {
+   public:
+    explicit Rockstar(const std::string& fname, ReaderConfig config = ReaderConfig()) : rd_(Open(fname, config)) {}
+    // Names, rockstar.go:16-23: the column names in the first line of the file
+    std::vector<std::string> Names() {
+        const std::string firstLine = rd_->LineHeader(1);
+        return firstLine.find("(0)") != std::string::npos ? consistentTreesNames(firstLine) : rockstarNames(firstLine);
+    }
+    static std::vector<std::string> rockstarNames(const std::string& line) {        // rockstar.go:25-36
+        std::vector<std::string> out;
+        size_t a = line.empty() ? 0 : 1;                                            // line[1:]: the comment character
+        while (a <= line.size()) {
+            size_t b = line.find(' ', a);
+            if (b == std::string::npos) b = line.size();
+            std::string tok = trim(line.substr(a, b - a));
+            if (!tok.empty()) out.push_back(tok);
+            a = b + 1;
+        }
+        return out;
+    }
+    static std::vector<std::string> consistentTreesNames(const std::string& line) { // rockstar.go:38-52: "name(12)" -> "name"
+        std::vector<std::string> names = rockstarNames(line);
+        for (std::string& n : names) {
+            const size_t p = n.rfind('(');
+            n = trim(p == std::string::npos ? std::string() : n.substr(0, p));
+        }
+        return names;                                                               // (the reference returns names, empty ones included)
+    }
+    void SetThreads(int n) { rd_->SetThreads(n); }
+    std::string Header() { return rd_->CommentHeader(); }
+    void SetNames(const std::vector<std::string>& names) { rd_->SetNames(names); }
+    int Blocks() const { return rd_->Blocks(); }
+    int64_t BlockSize(int b) const { return rd_->BlockSize(b); }
+    void Close() { rd_->Close(); }
+    BlockColumns Block(int b, const std::vector<std::string>& names, const std::vector<bool>& isInt) { return rd_->Block(b, names, isInt); }
+
+   private:
+    static std::string trim(const std::string& s) {                                 // strings.Trim(s, " \n\t")
+        size_t a = 0, b = s.size();
+        while (a < b && (s[a] == ' ' || s[a] == '\n' || s[a] == '\t')) ++a;
+        while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\n' || s[b - 1] == '\t')) --b;
+        return s.substr(a, b - a);
+    }
+    std::unique_ptr<Reader> rd_;
+};
+inline std::unique_ptr<Rockstar> OpenRockstar(const std::string& fname, ReaderConfig config = ReaderConfig()) { return std::make_unique<Rockstar>(fname, config); }
+
+}  // namespace text

@@ -247,6 +247,12 @@ class Context:
                                            capacity_rows, C.byref(n)))
         return n.value
 
+    def text_rows(self, data, sep, comment):
+        """(lines, lines kept) of a block of host text; the text_parse that directly follows on the same bytes object reuses the upload"""
+        nl, nr = C.c_int64(0), C.c_int64(0)
+        self._check(self._L.mnw_text_rows(self._h, data, len(data), sep, comment, C.byref(nl), C.byref(nr)))
+        return nl.value, nr.value
+
     def generic_cut(self, mass_ptr, cutoff, n, cols, stream=None):
         """GenericCut (scripts/text_to_minh.go:271-312): cols = [(src_ptr, dst_ptr, elem_bytes)] device columns -> rows kept"""
         arr = (CutColC * max(len(cols), 1))(*[CutColC(s, d, e, 0) for s, d, e in cols])

@@ -141,6 +141,9 @@ struct mnw_ctx {
     size_t cap_text = 0, cap_tile = 0;
     void* d_text = nullptr; void* d_tile = nullptr;
     void* d_tslow = nullptr; void* d_tstate = nullptr;
+    const uint8_t* text_res = nullptr;              // host text whose copy, tile counts and prefixes are on the device (mnw_text_rows)
+    int64_t text_res_n = 0, text_res_lines = 0, text_res_rows = 0;
+    uint8_t text_res_sep = 0, text_res_comm = 0;
     int64_t text_stats[3] = {0, 0, 0};              // of the last mnw_text_parse: lines, lines kept, tiles on the general path
 
     // exact path scratch
@@ -1312,6 +1315,49 @@ bool go_is_space(uint8_t ch) {      // unicode.IsSpace for the Latin-1 range, as
 }
 }  // namespace
 
+namespace {
+// the text on the device, lines / kept lines per tile counted and prefixed, totals on the host
+int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment, bool force) {
+    if (!force && c->text_res == text && c->text_res_n == nbytes && c->text_res_sep == sep && c->text_res_comm == comment) return MNW_OK;
+    c->text_res = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
+    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
+    if (rc) return rc;
+    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
+    if (rc) return rc;
+    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
+    if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
+    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    {
+        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
+        mnw::launch_text_count(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (int64_t*)c->d_tile);
+        mnw::launch_text_scan(s, (int64_t*)c->d_tile, tiles, (mnw::TextState*)c->d_tstate);
+    }
+    HIPCHK(c, hipGetLastError());
+    mnw::TextState st;
+    HIPCHK(c, hipMemcpyAsync(&st, c->d_tstate, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->text_res = text; c->text_res_n = nbytes; c->text_res_sep = sep; c->text_res_comm = comment;
+    c->text_res_lines = st.n_lines; c->text_res_rows = st.n_rows;
+    return MNW_OK;
+}
+}  // namespace
+
+int mnw_text_rows(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment, int64_t* n_lines, int64_t* n_rows) {
+    if (!c || nbytes < 0 || (nbytes > 0 && !text)) return fail(c, MNW_E_ARG, "text: bad arguments");
+    if (sep == '\n' || comment == '\n') return fail(c, MNW_E_ARG, "text: the newline cannot be the separator or the comment character");
+    if (n_lines) *n_lines = nbytes == 0 ? 1 : 0;
+    if (n_rows) *n_rows = 0;
+    if (nbytes == 0) return MNW_OK;
+    const int rc = text_load(c, text, nbytes, sep, comment, true);
+    if (rc) return rc;
+    if (n_lines) *n_lines = c->text_res_lines;
+    if (n_rows) *n_rows = c->text_res_rows;
+    return MNW_OK;
+}
+
 int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment,
                    const int32_t* float_cols, int n_float, float* const* float_out,
                    const int32_t* int_cols, int n_int, int64_t* const* int_out, int64_t capacity_rows, int64_t* n_rows) {
@@ -1363,23 +1409,16 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
-    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
+    int rc = text_load(c, text, nbytes, sep, comment, false);       // a no-op right after mnw_text_rows on the same buffer
     if (rc) return rc;
-    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
-    if (rc) return rc;
-    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
-    if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
+    c->text_res = nullptr;                                          // one use only: the caller may refill the same buffer with the next block
     mnw::TextState st0;
     memset(&st0, 0, sizeof st0);
     st0.err_line = ~0ull;
+    st0.n_rows = c->text_res_rows; st0.n_lines = c->text_res_lines;
     HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
     const uint8_t* dtext = (const uint8_t*)c->d_text;
-    {
-        ScopedTimer t(c, s, MNW_K_TEXT_LINES);
-        mnw::launch_text_count(s, dtext, nbytes, sep, comment, (int64_t*)c->d_tile);
-        mnw::launch_text_scan(s, (int64_t*)c->d_tile, tiles, (mnw::TextState*)c->d_tstate);
-    }
+    (void)tiles;
     {
         ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
         mnw::launch_text_parse(s, dtext, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
@@ -1472,6 +1511,7 @@ int mnw_generic_cut(mnw_ctx* c, mnw_stream_t stream, const float* mass, float cu
         if (cols[k].src == cols[k].dst) return fail(c, MNW_E_ARG, "cut: a column cannot be filtered in place");
     }
     const int64_t tiles = (n + mnw::kCutTile - 1) / mnw::kCutTile;
+    c->text_res = nullptr;                                          // the tile scratch is shared with the text passes
     int rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)(tiles + 1) * 8 + 16);
     if (rc) return rc;
     {
