@@ -16,6 +16,7 @@
 // thrown.  Not thread-safe, like the reference's Writer/Reader (one os.File with an implicit cursor).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -222,6 +223,11 @@ struct intGroup : group {
     // write(x) / read() of writeTail / newIntGroupFromTail (group.go:190-198, 216-225): a small int64
     // array stored as (min, bits, packed x-min) -- the same codec as a data block
     static void writeArray(std::FILE* f, const std::vector<int64_t>& x) {
+        if (x.size() == 1) {                 // min = x[0], x - min = {0}, PrecisionNeeded(0) = 0, no bytes (group.go:190-198, bit.go:162):
+            detail::binaryWrite(f, x[0]);    // minh writes one group per (block, column), so every tail array has one element
+            detail::binaryWrite(f, (int64_t)0);
+            return;
+        }
         std::vector<uint8_t> out(8 * x.size() + 16);
         int64_t mn = 0, b = 0, n = 0;
         detail::check(mnw_int_encode(detail::ctx(), x.data(), (int64_t)x.size(), &mn, &b, out.data(), (int64_t)out.size(), &n));
@@ -233,7 +239,8 @@ struct intGroup : group {
         int64_t mn, b;
         detail::binaryRead(f, mn); detail::binaryRead(f, b);
         std::vector<int64_t> out((size_t)blocks);
-        const size_t nb = b == 0 ? 0 : (size_t)bit::ArrayBytes((int)b, (int)blocks);
+        if (b == 0) { std::fill(out.begin(), out.end(), mn); return out; }      // no bytes: zeros (bit.go:171-174) + min (group.go:262)
+        const size_t nb = (size_t)bit::ArrayBytes((int)b, (int)blocks);
         std::vector<uint8_t> buf(nb);
         detail::fread_all(f, buf.data(), nb);
         detail::check(mnw_int_decode(detail::ctx(), buf.data(), (int64_t)nb, mn, b, blocks, out.data()));

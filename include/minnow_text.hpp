@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <cctype>
 
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "minnow.hpp"
 
 namespace text {
@@ -82,11 +85,13 @@ class Reader {
         if (names.size() != isInt.size()) throw Error("one type per name");
         if (b < 0 || b >= Blocks()) throw Error("block index out of range");
         mnw_ctx* ctx = minnow::detail::ctx();
-        buf_.resize((size_t)blockSizes_[(size_t)b]);
-        std::fseek(f_, (long)blockStarts_[(size_t)b], SEEK_SET);
-        minnow::detail::fread_all(f_, buf_.data(), buf_.size());
+        // rd.buf: the block's bytes.  The reference reads them into a buffer (text.go:183-187); here the file's pages are
+        // mapped and go to the device straight from the page cache -- no copy on the host at all
+        const Mapped block(fileno(f_), blockStarts_[(size_t)b], blockSizes_[(size_t)b]);
+        const uint8_t* const text = block.data;
+        const int64_t nbytes = blockSizes_[(size_t)b];
         int64_t lines = 0, rows = 0;
-        minnow::detail::check(mnw_text_rows(ctx, buf_.data(), (int64_t)buf_.size(), config_.Separator, config_.Comment, &lines, &rows));
+        minnow::detail::check(mnw_text_rows(ctx, text, nbytes, config_.Separator, config_.Comment, &lines, &rows));
         // splitByType, text.go:202-221
         std::vector<int32_t> fIdx, iIdx;
         std::vector<size_t> fAt, iAt;
@@ -118,7 +123,7 @@ class Reader {
             for (size_t k = 0; k < nf; ++k) fo[k] = static_cast<float*>(out.ptr[fAt[f0 + k]]);
             for (size_t k = 0; k < ni; ++k) io[k] = static_cast<int64_t*>(out.ptr[iAt[i0 + k]]);
             int64_t n = 0;
-            minnow::detail::check(mnw_text_parse(ctx, buf_.data(), (int64_t)buf_.size(), config_.Separator, config_.Comment,
+            minnow::detail::check(mnw_text_parse(ctx, text, nbytes, config_.Separator, config_.Comment,
                                                  fIdx.data() + f0, (int)nf, fo.data(), iIdx.data() + i0, (int)ni, io.data(), rows, &n));
             f0 += nf; i0 += ni;
         } while (f0 < fIdx.size() || i0 < iIdx.size());
@@ -126,6 +131,23 @@ class Reader {
     }
 
    private:
+    struct Mapped {                                     // [offset, offset + len) of a file, read-only
+        void* base = nullptr;
+        size_t maplen = 0;
+        const uint8_t* data = nullptr;
+        Mapped(int fd, int64_t offset, int64_t len) {
+            if (len <= 0) { static const uint8_t none = 0; data = &none; return; }
+            const int64_t page = (int64_t)sysconf(_SC_PAGESIZE), a = offset / page * page;
+            maplen = (size_t)(offset - a + len);
+            base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)a);
+            if (base == MAP_FAILED) { base = nullptr; throw Error("mmap of the text block failed"); }
+            data = static_cast<const uint8_t*>(base) + (offset - a);
+        }
+        ~Mapped() { if (base) munmap(base, maplen); }
+        Mapped(const Mapped&) = delete;
+        Mapped& operator=(const Mapped&) = delete;
+    };
+
     // findBlocks / nextBlock, text.go:82-131
     void findBlocks() {
         int64_t curr = 0;
@@ -179,7 +201,6 @@ class Reader {
     std::vector<int64_t> blockStarts_, blockSizes_;
     std::vector<std::string> names_;
     bool haveNames_ = false;
-    std::vector<uint8_t> buf_;
     std::vector<void*> dev_;
     std::vector<size_t> cap_;
 };

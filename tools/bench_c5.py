@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] shape on one GPU: text_to_minh of a Rockstar-style catalogue, end to end (text file -> .minh file),
+and the read back.  ROWS rows of 44 columns (4 ids, 20 logarithmic, 10 positions, 10 velocities) are written to a
+scratch file; tools/text_to_minh (C++ over include/minnow_text.hpp + minh.hpp) converts it with the reference's loop
+(Block -> GenericCut -> minh.Block); the oracle's restatement of text.Reader.Block is timed on a bounded sample beside
+it.  Prints one JSON object."""
+import json, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+gen_only = None
+if len(sys.argv) > 2 and sys.argv[1] == "--gen-only":        # write the catalogue and print the converter's command line (for rocprofv3)
+    gen_only = sys.argv[2]
+    del sys.argv[1:3]
+rows = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2 * 10**6
+max_block = int(float(sys.argv[2])) if len(sys.argv) > 2 else 5 * 2**30
+from test_text_to_minh_gpu import _build
+exe = _build()
+rng = np.random.default_rng(3)
+ids = rng.integers(0, 10**11, (rows, 4))
+logm = 10 ** rng.uniform(8, 15, (rows, 20))
+pos = rng.uniform(0, 250, (rows, 10))
+vel = rng.normal(0, 300, (rows, 10))
+cols = [ids[:, k].astype(str) for k in range(4)] + [np.char.mod("%.4e", logm[:, k]) for k in range(20)] + \
+       [np.char.mod("%.5f", pos[:, k]) for k in range(10)] + [np.char.mod("%.2f", vel[:, k]) for k in range(10)]
+lines = cols[0]
+for c in cols[1:]:
+    lines = np.char.add(np.char.add(lines, " "), c)
+names = ["id%d" % k for k in range(4)] + ["m%d" % k for k in range(20)] + ["x%d" % k for k in range(10)] + ["v%d" % k for k in range(10)]
+data = ("#" + " ".join(names) + "\n#a = 1.00000\n#synthetic catalogue\n" + "\n".join(lines.tolist()) + "\n").encode()
+if gen_only:
+    os.makedirs(gen_only, exist_ok=True)
+    tmp = gen_only
+else:
+    tmp = tempfile.mkdtemp(prefix="mnw_c5_")
+src, out = os.path.join(tmp, "hlist.txt"), os.path.join(tmp, "hlist.minh")
+open(src, "wb").write(data)
+spec = ["id%d:int" % k for k in range(4)] + ["m%d:log:1e8:1e16:0.01" % k for k in range(20)] + ["x%d:pos:0.001" % k for k in range(10)] + \
+       ["v%d:lin:-5000:5000:1" % k for k in range(10)]
+cmd = [exe, src, out, "250", "m0", "3e8", str(max_block)] + spec
+if gen_only:
+    print(" ".join(cmd))
+    sys.exit(0)
+best = None
+for rep in range(3):                                    # the file is in the page cache after the write; best of three
+    r = subprocess.run([exe, src, out, "250", "m0", "3e8", str(max_block)] + spec, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = json.loads(r.stdout)
+    if best is None or info["total_s"] < best["total_s"]:
+        best = info
+# the oracle (pure Python restatement of parse.go) on a bounded sample of the same text, one core
+from oracle import oracle
+sample = data[:data.index(b"\n", 6_000_000) + 1]
+t = time.perf_counter()
+oracle.text_block_parse(sample, ord(" "), ord("#"), list(range(4, 44)), list(range(4)))
+dt = time.perf_counter() - t
+best.update({"rows_generated": rows, "columns": 44, "bytes_per_row": len(data) / rows, "max_block_bytes": max_block,
+             "cpu_parse_baseline": {"value": len(sample) / dt / 1e9, "unit": "GB/s of text", "cores": 1, "kind": "port",
+                                    "sample": "%d bytes of the same text through the oracle's Python restatement of text.Reader.Block" % len(sample)}})
+print(json.dumps(best))
+for f in (src, out):
+    os.remove(f)
+os.rmdir(tmp)
