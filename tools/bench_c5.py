@@ -50,6 +50,9 @@ for rep in range(3):                                    # the file is in the pag
     info = json.loads(r.stdout)
     if best is None or info["total_s"] < best["total_s"]:
         best = info
+rb = subprocess.run([exe, "--read", out], capture_output=True, text=True, timeout=1200)
+assert rb.returncode == 0, rb.stdout + rb.stderr
+best["read_back"] = json.loads(rb.stdout)
 # the oracle (pure Python restatement of parse.go) on a bounded sample of the same text, one core
 from oracle import oracle
 sample = data[:data.index(b"\n", 6_000_000) + 1]

@@ -13,8 +13,11 @@
 //                        t[0] == "log" where it means t[1], text_to_minh.go:250, so its own files never set Log)
 //       pos              minh.Float, 0 / L / EPS     ("q_float position")
 //   text_to_minh --dump <file.minh>      reads a file back through minh::Reader and prints its columns as JSON
+//   text_to_minh --read <file.minh>      reads every column of every block back into device arrays (the reader side of the
+//                                        round trip: minh.Reader.IntBlock / FloatBlock per block) and prints the time
 //
 // Prints one JSON object with the time spent per stage.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -68,9 +71,47 @@ static int dump(const std::string& fname) {
     return 0;
 }
 
+static int readBack(const std::string& fname) {
+    mnw_ctx* ctx = minnow::detail::ctx();
+    mnw_timing_enable(ctx, 1);
+    const double t0 = now();
+    auto rd = minh::Open(fname);
+    std::vector<std::string> inames, fnames;
+    for (size_t i = 0; i < rd->Names.size(); ++i) {
+        const int64_t t = rd->Columns[i].Type;
+        if (t == minh::Int64 || t == minh::Int) inames.push_back(rd->Names[i]);
+        else if (t == minh::Float32 || t == minh::Float) fnames.push_back(rd->Names[i]);
+    }
+    int maxLen = 0;
+    for (int n : rd->BlockLengths) maxLen = std::max(maxLen, n);
+    std::vector<void*> di(inames.size()), df(fnames.size());
+    for (void*& p : di) minnow::detail::check(mnw_dev_alloc(ctx, 8ll * maxLen + 16, &p));
+    for (void*& p : df) minnow::detail::check(mnw_dev_alloc(ctx, 4ll * maxLen + 16, &p));
+    const double t1 = now();
+    int64_t outBytes = 0;
+    for (int b = 0; b < rd->Blocks; ++b) {
+        if (!inames.empty()) rd->IntBlockDevice(b, inames, di);
+        if (!fnames.empty()) rd->FloatBlockDevice(b, fnames, df);
+        outBytes += (int64_t)rd->BlockLengths[(size_t)b] * (int64_t)(8 * inames.size() + 4 * fnames.size());
+    }
+    const double t2 = now();
+    for (void* p : di) mnw_dev_free(ctx, p);
+    for (void* p : df) mnw_dev_free(ctx, p);
+    mnw_kernel_time kt[MNW_K_COUNT];
+    mnw_timing_get(ctx, kt);
+    double kms = 0;
+    for (int k = 0; k < MNW_K_COUNT; ++k) kms += kt[k].total_ms;
+    std::printf("{\"blocks\": %d, \"length\": %d, \"columns\": %zu, \"decoded_bytes\": %lld, \"open_s\": %.6f, \"blocks_s\": %.6f, "
+                "\"decoded_GBps\": %.4f, \"kernels_total_ms\": %.4f}\n", rd->Blocks, rd->Length, inames.size() + fnames.size(), (long long)outBytes,
+                t1 - t0, t2 - t1, (double)outBytes / (t2 - t1) / 1e9, kms);
+    rd->Close();
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc == 3 && std::string(argv[1]) == "--dump") return dump(argv[2]);
+        if (argc == 3 && std::string(argv[1]) == "--read") return readBack(argv[2]);
         if (argc < 8) { std::cerr << "usage: text_to_minh <in.txt> <out.minh> <L> <mass column> <cutoff> <max block bytes> COLUMN...\n"; return 2; }
         const std::string in = argv[1], out = argv[2], massName = argv[4];
         const float L = (float)std::atof(argv[3]);
