@@ -44,7 +44,7 @@ void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_selftest(hipStream_t, int, uint64_t, uint64_t, unsigned long long*);
 constexpr int kTextTile = 12288, kTextMaxCols = 256, kTextMaxOut = 48;
-struct TextCols { int16_t slot[kTextMaxCols]; float* fout[kTextMaxOut]; int64_t* iout[kTextMaxOut]; int32_t fields_expected; int32_t max_field; };
+struct TextCols { int16_t slot[kTextMaxCols]; void* out[2 * kTextMaxOut]; int32_t n_float, n_int; int32_t fields_expected; int32_t max_field; };
 struct TextSlow { int64_t row; int64_t offset; int32_t len; int32_t slot; };
 struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned int flags; long long n_rows; long long n_lines; unsigned int tiles_general; unsigned int pad; };
 void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, int64_t*);
@@ -1371,13 +1371,16 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
     memset(&cols, 0, sizeof cols);
     for (int k = 0; k < mnw::kTextMaxCols; ++k) cols.slot[k] = -1;
     cols.max_field = -1;
-    for (int k = 0; k < n_float + n_int; ++k) {
+    cols.n_float = n_float; cols.n_int = n_int;
+    for (int k = 0; k < n_float + n_int; ++k) {                      // output column k: the floats first, then the ints
         const bool isf = k < n_float;
         const int32_t f = isf ? float_cols[k] : int_cols[k - n_float];
         if (f < 0 || f >= mnw::kTextMaxCols) return fail(c, MNW_E_ARG, "text: field numbers must be in 0..255");
         if (cols.slot[f] != -1) return fail(c, MNW_E_ARG, "text: a field may be requested once");
-        if (isf) { if (!float_out[k]) return fail(c, MNW_E_ARG, "text: null output"); cols.slot[f] = (int16_t)k; cols.fout[k] = float_out[k]; }
-        else { if (!int_out[k - n_float]) return fail(c, MNW_E_ARG, "text: null output"); cols.slot[f] = (int16_t)(0x4000 + k - n_float); cols.iout[k - n_float] = int_out[k - n_float]; }
+        void* const o = isf ? (void*)float_out[k] : (void*)int_out[k - n_float];
+        if (!o) return fail(c, MNW_E_ARG, "text: null output");
+        cols.slot[f] = (int16_t)k;
+        cols.out[k] = o;
         if (f > cols.max_field) cols.max_field = f;
     }
     // bufLen = len(bytes.Fields(lines[0])) (parse.go:96): words of the first kept line, split at white space

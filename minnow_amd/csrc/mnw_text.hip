@@ -12,10 +12,13 @@
 //                  comment) and from then on lines and fields are bit arithmetic: field starts = content bits whose
 //                  predecessor is no content; the line of a field = newlines before it (prefix sum over the threads);
 //                  its number inside the line = field starts since the last newline (a segmented prefix sum); its output
-//                  row = owned non-empty lines that ended before it (prefix sum).  Wanted fields are put on a list in LDS
-//                  and converted ONE FIELD PER THREAD, so the lanes stay busy whatever the lines look like.
+//                  row = owned non-empty lines that ended before it (prefix sum).  The start of every wanted field goes
+//                  into a table in LDS, [column][line], and the fields are converted ONE FIELD PER THREAD in table order:
+//                  the lanes stay busy whatever the lines look like, neighbouring lanes convert neighbouring rows of one
+//                  column -- the same code path, stores into the same lines -- and a token is converted out of four
+//                  registers holding its first 16 bytes, without loops or branches.
 //                  A tile that holds a comment character, a line that does not end inside the staged text, more than
-//                  2,048 kept lines or more wanted fields than the list holds takes the general path: one thread per
+//                  2,048 kept lines or more wanted fields than the table holds takes the general path: one thread per
 //                  line, walking it byte by byte as the reference does.
 //
 // Numbers: a decimal literal whose digits fit 2^53 and whose power of ten is within 10^+-22 is converted with ONE
@@ -28,15 +31,15 @@
 constexpr int kTextTile = 12288;          // bytes of text whose line starts one workgroup owns
 constexpr int kTextRegion = 16384;        // bytes a workgroup stages: 256 threads x 64
 constexpr int kTextLead = 16;             // staged bytes in front of the tile (the byte before the tile decides whether a line starts at its first byte)
-constexpr int kTextRecCap = 3072;         // wanted fields per tile on the fast path
-constexpr int kTextMaxRowOff = 2048;      // kept lines per tile on the fast path (11 bits of a record)
+constexpr int kTextRecCap = 6144;         // wanted fields per tile on the fast path (kept lines x wanted columns)
+constexpr int kTextMaxRowOff = 2048;      // kept lines per tile on the fast path
 constexpr int kTextMaxCols = 256;         // fields per line that can be addressed
 constexpr int kTextMaxOut = 48;           // requested columns of each type
 
 struct TextCols {
-    int16_t slot[kTextMaxCols];           // field -> -1 (not wanted) | float slot | 0x4000 + int slot
-    float* fout[kTextMaxOut];
-    int64_t* iout[kTextMaxOut];
+    int16_t slot[kTextMaxCols];           // field -> -1 (not wanted) | output column: 0 .. n_float-1 float32, n_float .. n_float+n_int-1 int64
+    void* out[2 * kTextMaxOut];           // output column -> device array
+    int32_t n_float, n_int;
     int32_t fields_expected;              // every line must have this many fields (parse.go:96-103)
     int32_t max_field;                    // highest wanted field: the rest of the line is only counted
 };
@@ -202,91 +205,24 @@ __device__ __forceinline__ void text_error(TextState* st, int64_t line, int code
     atomicMin(&st->err_line, ((unsigned long long)(line + 1) << 8) | (unsigned)code);
 }
 
-// strconv.Atoi: optional sign, decimal digits, must fit int64 (int is 64 bits on the reference's platforms)
-__device__ __forceinline__ bool text_atoi(const uint8_t* __restrict__ p, int len, int64_t* out) {
-    int i = 0;
-    bool neg = false;
-    if (len > 0 && (p[0] == '+' || p[0] == '-')) { neg = p[0] == '-'; i = 1; }
-    if (i >= len) return false;
-    uint64_t v = 0;
-    for (; i < len; ++i) {
-        const uint32_t d = (uint32_t)p[i] - '0';
-        if (d > 9) return false;
-        if (v > (0x7fffffffffffffffull + (neg ? 1 : 0) - d) / 10) return false;       // overflow: Atoi reports a range error
-        v = v * 10 + d;
-    }
-    *out = neg ? (int64_t)(0 - v) : (int64_t)v;
-    return true;
-}
+#include "mnw_text_num.h"
 
-__device__ const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
-                                      1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
-
-// 0: converted (exactly as strconv.ParseFloat(s, 64) would), 1: leave to the host, 2: syntax error
-__device__ __forceinline__ int text_atof(const uint8_t* __restrict__ p, int len, double* out) {
-    int i = 0;
-    bool neg = false;
-    if (len > 0 && (p[0] == '+' || p[0] == '-')) { neg = p[0] == '-'; i = 1; }
-    if (i >= len) return 2;
-    const uint32_t c0 = p[i] | 0x20;
-    if (c0 == 'i' || c0 == 'n') return 1;                      // inf / infinity / nan: the host decides
-    uint64_t m = 0;
-    int nd = 0, dropped = 0, e10 = 0;
-    bool seen_digit = false, seen_dot = false, inexact = false;
-    for (; i < len; ++i) {
-        const uint8_t c = p[i];
-        if (c == '.') { if (seen_dot) return 2; seen_dot = true; continue; }
-        const uint32_t d = (uint32_t)c - '0';
-        if (d > 9) break;
-        seen_digit = true;
-        if (m == 0 && d == 0) { if (seen_dot) --e10; continue; }           // leading zeros
-        if (nd < 19) { m = m * 10 + d; ++nd; if (seen_dot) --e10; }
-        else { if (d) inexact = true; ++dropped; if (!seen_dot) ++e10; }
-    }
-    (void)dropped;
-    if (!seen_digit) return (i < len && (p[i] | 0x20) == 'x') ? 1 : 2;
-    if (i < len) {
-        const uint32_t c = p[i] | 0x20;
-        if (c == 'x' || p[i] == '_') return 1;                               // hex floats, digit separators: host
-        if (c != 'e') return 2;
-        ++i;
-        bool eneg = false;
-        if (i < len && (p[i] == '+' || p[i] == '-')) { eneg = p[i] == '-'; ++i; }
-        if (i >= len) return 2;
-        int ex = 0;
-        for (; i < len; ++i) {
-            const uint32_t d = (uint32_t)p[i] - '0';
-            if (d > 9) return p[i] == '_' ? 1 : 2;
-            if (ex < 100000) ex = ex * 10 + (int)d;
-        }
-        e10 += eneg ? -ex : ex;
-    }
-    double v;
-    if (m == 0) v = 0.0;
-    else if (inexact || m >= (1ull << 53)) return 1;
-    else if (e10 >= 0 && e10 <= 22) v = __dmul_rn((double)m, kPow10[e10]);
-    else if (e10 < 0 && e10 >= -22) v = __ddiv_rn((double)m, kPow10[-e10]);
-    else return 1;
-    *out = neg ? -v : v;
-    return 0;
-}
-
-// one wanted field -> its output; tok[0, len) through a flat pointer (LDS or global)
-__device__ __forceinline__ void text_convert(const uint8_t* tok, int len, int sl, int64_t row, int64_t line, int64_t offset,
-                                             float* const* fout, int64_t* const* iout, int64_t capacity,
+// one wanted field -> its output (general functions); tok[0, len) through a flat pointer (LDS or global)
+__device__ __forceinline__ void text_convert(const uint8_t* tok, int len, int col, int n_float, int64_t row, int64_t line, int64_t offset,
+                                             void* const* outp, int64_t capacity,
                                              TextSlow* __restrict__ slow, unsigned int slow_cap, TextState* __restrict__ st) {
     if (row >= capacity) { atomicOr(&st->flags, 1u); return; }
-    if (sl >= 0x4000) {
+    if (col >= n_float) {
         int64_t x;
-        if (text_atoi(tok, len, &x)) iout[sl - 0x4000][row] = x;
+        if (text_atoi(tok, len, &x)) static_cast<int64_t*>(outp[col])[row] = x;
         else text_error(st, line, kTextErrInt);
     } else {
         double x;
         const int rc = text_atof(tok, len, &x);
-        if (rc == 0) fout[sl][row] = (float)x;                                      // float32(x), parse.go:165
+        if (rc == 0) static_cast<float*>(outp[col])[row] = (float)x;                 // float32(x), parse.go:165
         else if (rc == 1) {
             const unsigned k = atomicAdd(&st->n_slow, 1u);
-            if (k < slow_cap) { TextSlow w = {row, offset, (int32_t)len, sl}; slow[k] = w; }
+            if (k < slow_cap) { TextSlow w = {row, offset, (int32_t)len, col}; slow[k] = w; }
         } else text_error(st, line, kTextErrFloat);
     }
 }
@@ -294,21 +230,27 @@ __device__ __forceinline__ void text_convert(const uint8_t* tok, int len, int sl
 __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ text, int64_t n, uint8_t sep, uint8_t comm,
                                                     const int64_t* __restrict__ tile_base, TextCols cols, int64_t capacity,
                                                     TextSlow* __restrict__ slow, unsigned int slow_cap, TextState* __restrict__ st) {
-    __shared__ __attribute__((aligned(16))) uint8_t region[kTextRegion];
-    __shared__ uint32_t rec[kTextRecCap];
+    __shared__ __attribute__((aligned(16))) uint8_t region[kTextRegion + 32];      // (+32: a token's 16-byte window may reach behind the end)
+    __shared__ __attribute__((aligned(16))) uint16_t rec[kTextRecCap];      // rec[column * kept lines + line] = where the field starts
     __shared__ int16_t s_slot[kTextMaxCols];
-    __shared__ float* s_fout[kTextMaxOut];
-    __shared__ int64_t* s_iout[kTextMaxOut];
+    __shared__ void* s_out[2 * kTextMaxOut];
+    __shared__ double s_p10[23];
     __shared__ int wsum[4];
     __shared__ uint32_t wseg[4];
-    __shared__ unsigned int s_nrec, s_flags, s_nown;
+    __shared__ unsigned int s_flags, s_nown;
 
     const int t = threadIdx.x;
     const int64_t R = (int64_t)blockIdx.x * kTextTile - kTextLead;
     const int64_t line_base = tile_base[2 * (int64_t)blockIdx.x], row_base = tile_base[2 * (int64_t)blockIdx.x + 1];
-    if (t == 0) { s_nrec = 0; s_flags = 0; s_nown = 0; }
+    if (t == 0) { s_flags = 0; s_nown = 0; }
     s_slot[t] = cols.slot[t];
-    if (t < kTextMaxOut) { s_fout[t] = cols.fout[t]; s_iout[t] = cols.iout[t]; }
+    if (t < 2 * kTextMaxOut) s_out[t] = cols.out[t];
+    if (t < 23) s_p10[t] = text_pow10(t);
+    if (t < 8) reinterpret_cast<uint32_t*>(region + kTextRegion)[t] = 0x0a0a0a0au;
+    // every table entry starts out as "no such field": a line with too few fields (an error the host reports) leaves holes
+    static_assert(kTextRecCap * 2 == 256 * 48, "three 16-byte stores per thread cover the table");
+#pragma unroll
+    for (int k = 0; k < 3; ++k) reinterpret_cast<u32x4*>(rec)[3 * t + k] = u32x4{~0u, ~0u, ~0u, ~0u};
     u32x4 w[4];
     text_load_chunk(text, n, R + 64 * t, w);
 #pragma unroll
@@ -322,8 +264,10 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
     int nl_total;
     const int nl_before = block_exclusive_scan(__popcll(nlm), wsum, &nl_total);      // (its barriers publish s_flags / s_nown)
     const int nown = (int)s_nown;
+    const int n_float = cols.n_float, n_want = cols.n_float + cols.n_int;
     // general path: a comment somewhere in the staged text, or the tile's last line does not end inside it
     bool general = (s_flags & 1u) || (nown > 0 && nl_total < nown + 1);
+    int vtotal = 0;
 
     if (!general) {
         const uint8_t prevb = t ? region[64 * t - 1] : (uint8_t)'\n';
@@ -363,9 +307,8 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
                 cnt_in = 0; prev = b; ++j;
             }
         }
-        int vtotal;
         const int vbase = block_exclusive_scan(__popcll(validend), wsum, &vtotal);
-        if (vtotal > kTextMaxRowOff) general = true;
+        if (vtotal > kTextMaxRowOff || vtotal * n_want > kTextRecCap) general = true;
         else {
             uint64_t m = start;
             while (m) {
@@ -377,41 +320,59 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
                 if (l < 1 || l > nown) continue;
                 const int fidx = nlb ? __popcll(start & below & bits_from(64 - __builtin_clzll(nlb))) : carry_cnt + __popcll(start & below);
                 if (fidx > cols.max_field) continue;
-                const int sl = s_slot[fidx];
-                if (sl < 0) continue;
-                const uint32_t rowoff = (uint32_t)(vbase + __popcll(validend & below));
-                const uint32_t code = sl >= 0x4000 ? 64u + (uint32_t)(sl - 0x4000) : (uint32_t)sl;
-                const unsigned k = atomicAdd(&s_nrec, 1u);
-                if (k < (unsigned)kTextRecCap) rec[k] = (uint32_t)(64 * t + b) | (rowoff << 14) | (code << 25);
+                const int col = s_slot[fidx];
+                if (col < 0) continue;
+                const int rowoff = vbase + __popcll(validend & below);
+                rec[col * vtotal + rowoff] = (uint16_t)(64 * t + b);
             }
             __syncthreads();
-            if (s_nrec > (unsigned)kTextRecCap) general = true;
         }
     }
 
     if (!general) {
-        const unsigned nrec = s_nrec;
-        for (unsigned k = t; k < nrec; k += 256) {
-            const uint32_t r = rec[k];
-            const int pos = (int)(r & 0x3fffu);
-            const int64_t row = row_base + ((r >> 14) & 0x7ffu);
-            const uint32_t code = r >> 25;
-            const uint8_t* tok = region + pos;
-            int len = 0;
-            while (pos + len < kTextRegion && tok[len] != sep && tok[len] != '\n') ++len;
+        // one field per thread, column after column (float columns first): neighbouring lanes convert neighbouring rows of the
+        // same column, so they run the same code and their stores fall into the same lines
+        const int total = vtotal * n_want, nfrec = vtotal * n_float;
+        const float inv = 1.0f / (float)(vtotal > 0 ? vtotal : 1);
+        const uint32_t sep4 = 0x01010101u * sep;
+        for (int k = t; k < total; k += 256) {
+            const int col = (int)(((float)k + 0.5f) * inv);               // k / vtotal, exact for k < 2^21
+            const int64_t row = row_base + (k - col * vtotal);
+            const int pos = rec[k];
+            if (pos == 0xffff) continue;                                  // a hole: the line's field count is wrong, already flagged
+            // the token's first 16 bytes
+            const uint32_t* d = reinterpret_cast<const uint32_t*>(region) + (pos >> 2);
+            const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+            const uint32_t sh = (uint32_t)pos & 3u;
+            uint32_t tw[4];
+            tw[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); tw[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            tw[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); tw[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            uint32_t ends = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ends |= (text_eq4(tw[q], sep4) | text_eq4(tw[q], 0x0a0a0a0au)) << (4 * q);
+            int len = ends ? __builtin_ctz(ends) : 17;
             if (row >= capacity) { atomicOr(&st->flags, 1u); continue; }
             int bad = 0;
-            if (code >= 64u) {
+            if (k >= nfrec) {
                 int64_t x;
-                if (text_atoi(tok, len, &x)) s_iout[code - 64u][row] = x;
+                bool ok = len <= 16 && fast_atoi16(tw, len, &x);
+                if (!ok) {
+                    if (len > 16) { len = 16; while (pos + len < kTextRegion && region[pos + len] != sep && region[pos + len] != '\n') ++len; }
+                    ok = text_atoi(region + pos, len, &x);
+                }
+                if (ok) static_cast<int64_t*>(s_out[col])[row] = x;
                 else bad = kTextErrInt;
             } else {
                 double x;
-                const int rc = text_atof(tok, len, &x);
-                if (rc == 0) s_fout[code][row] = (float)x;                                  // float32(x), parse.go:165
+                int rc = len <= 16 ? fast_atof16(tw, len, s_p10, &x) : 1;
+                if (rc != 0) {
+                    if (len > 16) { len = 16; while (pos + len < kTextRegion && region[pos + len] != sep && region[pos + len] != '\n') ++len; }
+                    rc = text_atof(region + pos, len, &x);
+                }
+                if (rc == 0) static_cast<float*>(s_out[col])[row] = (float)x;                 // float32(x), parse.go:165
                 else if (rc == 1) {
                     const unsigned q = atomicAdd(&st->n_slow, 1u);
-                    if (q < slow_cap) { TextSlow ws = {row, R + pos, (int32_t)len, (int32_t)code}; slow[q] = ws; }
+                    if (q < slow_cap) { TextSlow ws = {row, R + pos, (int32_t)len, (int32_t)col}; slow[q] = ws; }
                 } else bad = kTextErrFloat;
             }
             if (bad) {                                          // the line number is only needed here: the newlines in front of the field
@@ -454,8 +415,8 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
             const int64_t t0 = p;
             while (p < ll && lb[p] != sep) ++p;
             if (field <= cols.max_field && field < kTextMaxCols) {
-                const int sl = s_slot[field];
-                if (sl >= 0) text_convert(lb + t0, (int)(p - t0), sl, row, line, a + t0, s_fout, s_iout, capacity, slow, slow_cap, st);
+                const int col = s_slot[field];
+                if (col >= 0) text_convert(lb + t0, (int)(p - t0), col, n_float, row, line, a + t0, s_out, capacity, slow, slow_cap, st);
             }
             ++field;
         }

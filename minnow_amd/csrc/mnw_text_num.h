@@ -1,0 +1,171 @@
+// Number conversions of the text catalogue ingest (go/text/parse.go:126-170: strconv.Atoi, float32(strconv.ParseFloat(s, 64))).
+// Pure functions of their arguments, written so that they compile for the device (included by mnw_text.hip) and for the
+// host (tests/test_text_num_cpu.py builds them with g++ and checks them against correctly rounded conversions) -- the host
+// build is a test harness, not a code path of the library.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MNW_TN __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MNW_DMUL(a, b) __dmul_rn(a, b)
+#define MNW_DDIV(a, b) __ddiv_rn(a, b)
+#else
+#define MNW_DMUL(a, b) ((a) * (b))
+#define MNW_DDIV(a, b) ((a) / (b))
+#endif
+#else
+#define MNW_TN static inline
+#define MNW_DMUL(a, b) ((a) * (b))      /* IEEE double, no contraction possible in a single operation */
+#define MNW_DDIV(a, b) ((a) / (b))
+#endif
+
+// 10^k, 0 <= k <= 22: the powers of ten a float64 holds exactly
+MNW_TN double text_pow10(int k) {
+    const double t[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                          1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    return t[k];
+}
+
+// Both general conversions are single loops over the token without early exits: every character updates a few state
+// words and a verdict.  (An earlier form with break / continue / return inside the loops was compiled into code that
+// returned "syntax error" for every literal with an exponent when the token was read through a global pointer, while the
+// same source read through an LDS pointer worked: tools/microbench/text_num_dev.hip shows it and guards this form.)
+
+// strconv.Atoi: optional sign, decimal digits, must fit int64 (int is 64 bits on the reference's platforms)
+MNW_TN bool text_atoi(const uint8_t* p, int len, int64_t* out) {
+    const bool sgn = len > 0 && (p[0] == '+' || p[0] == '-');
+    const bool neg = sgn && p[0] == '-';
+    const int i0 = sgn ? 1 : 0;
+    const uint64_t limit = 0x7fffffffffffffffull + (neg ? 1u : 0u);       // |value| may reach 2^63 for a negative literal
+    uint64_t v = 0;
+    bool bad = i0 >= len;
+    for (int i = i0; i < len; ++i) {
+        const uint32_t d = (uint32_t)p[i] - '0';
+        const bool isd = d <= 9u;
+        // v * 10 + d > limit  <=>  v > (limit - d) / 10 : Atoi reports a range error
+        const bool over = isd && v > (limit - d) / 10;
+        bad = bad || !isd || over;
+        v = bad ? v : v * 10 + d;
+    }
+    *out = neg ? (int64_t)(0 - v) : (int64_t)v;
+    return !bad;
+}
+
+// 0: converted (exactly as strconv.ParseFloat(s, 64) would), 1: leave to the host, 2: syntax error
+MNW_TN int text_atof(const uint8_t* p, int len, double* out) {
+    const bool sgn = len > 0 && (p[0] == '+' || p[0] == '-');
+    const bool neg = sgn && p[0] == '-';
+    const int i0 = sgn ? 1 : 0;
+    if (i0 >= len) return 2;
+    const uint32_t c0 = p[i0] | 0x20u;
+    if (c0 == 'i' || c0 == 'n') return 1;                      // inf / infinity / nan: the host decides
+    uint64_t m = 0;
+    int nd = 0, e10 = 0, ex = 0, exp_pos = -2, verdict = 0;
+    bool seen_dot = false, seen_digit = false, in_exp = false, eneg = false, exp_digit = false, inexact = false;
+    for (int i = i0; i < len; ++i) {
+        const uint32_t c = p[i], d = c - '0';
+        const bool isd = d <= 9u;
+        const bool live = verdict == 0;
+        const bool mant = live && !in_exp, expo = live && in_exp;
+        const bool is_e = (c | 0x20u) == 'e' && seen_digit;
+        const bool is_esign = i == exp_pos + 1 && (c == '+' || c == '-');
+        // mantissa: at most 19 digits are kept, further ones only move the decimal point (and make the literal inexact)
+        const bool lead0 = m == 0 && d == 0;                                   // leading zeros
+        const bool keep = mant && isd && !lead0 && nd < 19, drop = mant && isd && !lead0 && nd >= 19;
+        m = keep ? m * 10 + d : m;
+        nd += keep ? 1 : 0;
+        e10 += (mant && isd && seen_dot && !drop) ? -1 : 0;
+        e10 += (drop && !seen_dot) ? 1 : 0;
+        inexact = inexact || (drop && d != 0);
+        seen_digit = seen_digit || (mant && isd);
+        // exponent (in_exp as it was before this character)
+        ex = (expo && isd && ex < 100000) ? ex * 10 + (int)d : ex;
+        exp_digit = exp_digit || (expo && isd);
+        eneg = eneg || (expo && !isd && is_esign && c == '-');
+        // everything else
+        int v = 0;
+        if (mant && !isd) {
+            if (c == '.') v = seen_dot ? 2 : 0;
+            else if (is_e) v = 0;
+            else if (c == '_' || (c | 0x20u) == 'x') v = 1;                    // digit separators, hex floats: host
+            else v = 2;
+        }
+        if (expo && !isd && !is_esign) v = c == '_' ? 1 : 2;
+        if (mant && !isd && c != '.' && is_e) { in_exp = true; exp_pos = i; }
+        seen_dot = seen_dot || (mant && c == '.');
+        verdict = live ? v : verdict;
+    }
+    if (verdict) return verdict;
+    if (!seen_digit || (in_exp && !exp_digit)) return 2;
+    e10 += eneg ? -ex : ex;
+    double v;
+    if (m == 0) v = 0.0;
+    else if (inexact || m >= (1ull << 53)) return 1;
+    else if (e10 >= 0 && e10 <= 22) v = MNW_DMUL((double)m, text_pow10(e10));
+    else if (e10 < 0 && e10 >= -22) v = MNW_DDIV((double)m, text_pow10(-e10));
+    else return 1;
+    *out = neg ? -v : v;
+    return 0;
+}
+
+// ---- a token of at most 16 bytes held in four registers (byte i = bits 8(i & 3).. of w[i >> 2]) ------------------------
+// The conversions below are the straight-line forms of text_atoi / text_atof for the tokens a catalogue is made of; they
+// give up (false / 1) on anything else and the caller then asks the general functions above, which decide between
+// value, host list and error.  Sixteen digits cannot overflow an int64 or exceed the 19 digits text_atof keeps.
+MNW_TN uint32_t tok_byte(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+
+MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out) {
+    const uint32_t c0 = w[0] & 0xffu;
+    const bool sgn = c0 == '+' || c0 == '-', neg = c0 == '-';
+    uint64_t v = 0;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t d = tok_byte(w, i) - '0';
+        const bool act = i < len && !(i == 0 && sgn);
+        bad |= act && d > 9u;
+        v = act ? v * 10 + d : v;
+    }
+    if (bad || len - (sgn ? 1 : 0) <= 0) return false;
+    *out = neg ? (int64_t)(0 - v) : (int64_t)v;
+    return true;
+}
+
+MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, double* out) {
+    const uint32_t c0 = w[0] & 0xffu;
+    const bool sgn = c0 == '+' || c0 == '-', neg = c0 == '-';
+    uint64_t m = 0;
+    int e10 = 0, ex = 0, exp_pos = -2;
+    bool seen_dot = false, seen_digit = false, in_exp = false, eneg = false, exp_digit = false, bad = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t c = tok_byte(w, i), d = c - '0';
+        const bool isd = d <= 9u;
+        const bool act = i < len && !(i == 0 && sgn);
+        const bool mant = act && !in_exp, expo = act && in_exp;
+        const bool is_dot = c == '.' && !seen_dot, is_e = (c | 0x20u) == 'e' && seen_digit;
+        const bool is_esign = i == exp_pos + 1 && (c == '+' || c == '-');
+        bad |= (mant && !isd && !is_dot && !is_e) || (expo && !isd && !is_esign);
+        // exponent part first: it tests in_exp as it was before this character
+        ex = (expo && isd) ? (ex > 99999 ? ex : ex * 10 + (int)d) : ex;
+        exp_digit |= expo && isd;
+        eneg |= expo && is_esign && c == '-';
+        m = (mant && isd) ? m * 10 + d : m;
+        e10 -= (mant && isd && seen_dot) ? 1 : 0;
+        seen_digit |= mant && isd;
+        if (mant && !isd && is_e) { in_exp = true; exp_pos = i; }
+        seen_dot |= mant && !isd && is_dot;
+    }
+    if (bad || !seen_digit || (in_exp && !exp_digit)) return 1;
+    e10 += eneg ? -ex : ex;
+    double v;
+    if (m == 0) v = 0.0;
+    else if (m >> 53) return 1;
+    else if (e10 >= 0 && e10 <= 22) v = MNW_DMUL((double)m, p10[e10]);
+    else if (e10 < 0 && e10 >= -22) v = MNW_DDIV((double)m, p10[-e10]);
+    else return 1;
+    *out = neg ? -v : v;
+    return 0;
+}
+

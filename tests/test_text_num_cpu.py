@@ -1,0 +1,107 @@
+"""The number conversions of the text ingest (minnow_amd/csrc/mnw_text_num.h: strconv.Atoi, strconv.ParseFloat restated for
+the device) compiled for the HOST and compared with Python's int() / float() -- exact and correctly rounded, like the Go
+functions, hence the same values.  Covers the general byte-wise forms and the register forms the kernel's fast path uses:
+whenever a register form returns a value it must be the right one, and whenever it gives up the general form decides."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "text_num_harness.cpp")
+HDR = os.path.join(ROOT, "minnow_amd", "csrc", "mnw_text_num.h")
+LIB = os.path.join(ROOT, "tests", "cpp", "libtext_num_harness.so")
+
+
+@pytest.fixture(scope="module")
+def tn():
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB])
+    L = C.CDLL(LIB)
+    for f in ("tn_atoi", "tn_fast_atoi"):
+        getattr(L, f).argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
+    for f in ("tn_atof", "tn_fast_atof"):
+        getattr(L, f).argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_double)]
+    return L
+
+
+def _go_float_ok(s):
+    """does strconv.ParseFloat accept s as a plain decimal literal (the subset the device decides itself)"""
+    try:
+        float(s)
+    except ValueError:
+        return False
+    return "_" not in s and s.strip() == s and not any(c in s.lower() for c in "xinfa")
+
+
+def _check_float(tn, s):
+    b = s.encode()
+    x = C.c_double()
+    rc = tn.tn_atof(b, len(b), C.byref(x))
+    if rc == 0:
+        assert _go_float_ok(s), s
+        want = float(s)
+        assert x.value == want and math.copysign(1, x.value) == math.copysign(1, want), (s, x.value, want)
+    elif rc == 2:
+        assert not _go_float_ok(s), s                      # a syntax error only where Go reports one
+    if len(b) <= 16:
+        y = C.c_double()
+        frc = tn.tn_fast_atof(b, len(b), C.byref(y))
+        if frc == 0:
+            assert rc == 0 and y.value == x.value and math.copysign(1, y.value) == math.copysign(1, x.value), (s, y.value, x.value)
+    return rc
+
+
+def _check_int(tn, s):
+    b = s.encode()
+    x = C.c_int64()
+    ok = tn.tn_atoi(b, len(b), C.byref(x))
+    try:
+        want = int(s) if ("_" not in s and s.strip() == s) else None
+    except ValueError:
+        want = None
+    if want is not None and not -2**63 <= want < 2**63:
+        want = None
+    assert bool(ok) == (want is not None), s
+    if ok:
+        assert x.value == want, s
+    if len(b) <= 16:
+        y = C.c_int64()
+        if tn.tn_fast_atoi(b, len(b), C.byref(y)):
+            assert ok and y.value == x.value, s
+
+
+def test_float_literals(tn):
+    fixed = ["0", "-0", "0.0", "1", "-1.5", "+2.5", "1e22", "1e23", "9007199254740993", "9007199254740992", "0.1", "0.3", ".5", "5.", "1E5", "1e+5",
+             "1e-5", "123456.789e3", "0.00001e-20", "4.929148e+11", "190.24664", "-493172645126", "1.7976931348623157e308", "4.9e-324", "1e-45",
+             "1e39", "16777217", "0.000000000000001", "1234567890123456", "12345678901234567", "00000000000001.5", "1e0000000000005",
+             "", "+", "-", ".", "e5", ".e5", "1e", "1e+", "1e+-5", "1..2", "1.2.3", "--1", "1-", "1e5.5", "abc", "1x", "0x10", "inf", "nan", "1_000", " 1", "1 "]
+    for s in fixed:
+        _check_float(tn, s)
+    rng = np.random.default_rng(17)
+    n_value = 0
+    for fmt, scale in (("%.4e", 1e12), ("%.5f", 250.0), ("%.2f", 3000.0), ("%g", 300.0), ("%.17g", 1.0), ("%.10e", 1e-10), ("%.6e", 1e30), ("%.3f", 1e9)):
+        for v in rng.standard_normal(4000) * scale:
+            n_value += _check_float(tn, fmt % v) == 0
+    for _ in range(4000):                                  # every mantissa / exponent the fast path covers, and its edges
+        m = int(rng.integers(0, 2**53 + 5))
+        e = int(rng.integers(-24, 25))
+        n_value += _check_float(tn, "%de%d" % (m, e)) == 0
+        s = str(m)
+        k = int(rng.integers(0, len(s) + 1))
+        n_value += _check_float(tn, s[:k] + "." + s[k:]) == 0
+    assert n_value > 30000
+
+
+def test_int_literals(tn):
+    for s in ["0", "-0", "+0", "1", "-1", "+17", "9223372036854775807", "9223372036854775808", "-9223372036854775808", "-9223372036854775809",
+              "99999999999999999999", "0000000000000000000001", "1234567890123456", "12345678901234567", "-493172645126",
+              "", "+", "-", "1.5", "1e5", "--1", "1-", "12a", "a12", " 1", "1 ", "1_000", "0x10"]:
+        _check_int(tn, s)
+    rng = np.random.default_rng(3)
+    for bits in range(1, 64):
+        for v in rng.integers(-2**bits, 2**bits, 50):
+            _check_int(tn, str(int(v)))
