@@ -335,13 +335,15 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
         const int total = vtotal * n_want, nfrec = vtotal * n_float;
         const float inv = 1.0f / (float)(vtotal > 0 ? vtotal : 1);
         const uint32_t sep4 = 0x01010101u * sep;
-        for (int k = t; k < total; k += 256) {
-            const int col = (int)(((float)k + 0.5f) * inv);               // k / vtotal, exact for k < 2^21
+        for (int kb = 0; kb < total; kb += 256) {                             // (every lane makes every trip: the wave-wide maximum below)
+            const int k = kb + t;
+            const bool have = k < total;
+            const int col = have ? (int)(((float)k + 0.5f) * inv) : 0;       // k / vtotal, exact for k < 2^21
             const int64_t row = row_base + (k - col * vtotal);
-            const int pos = rec[k];
-            if (pos == 0xffff) continue;                                  // a hole: the line's field count is wrong, already flagged
+            const int pos = have ? rec[k] : 0xffff;
+            const bool hole = pos == 0xffff;                                  // no such field: the line's field count is wrong, already flagged
             // the token's first 16 bytes
-            const uint32_t* d = reinterpret_cast<const uint32_t*>(region) + (pos >> 2);
+            const uint32_t* d = reinterpret_cast<const uint32_t*>(region) + ((pos & 0x3fff) >> 2);
             const uint32_t d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
             const uint32_t sh = (uint32_t)pos & 3u;
             uint32_t tw[4];
@@ -351,11 +353,17 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; ++q) ends |= (text_eq4(tw[q], sep4) | text_eq4(tw[q], 0x0a0a0a0au)) << (4 * q);
             int len = ends ? __builtin_ctz(ends) : 17;
+            // the longest token of the wave bounds the conversion loops (a column's tokens have much the same length)
+            int bound = (hole || len > 16) ? 0 : len;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(bound, o); bound = u > bound ? u : bound; }
+            bound = __builtin_amdgcn_readfirstlane(bound);
+            if (hole) continue;
             if (row >= capacity) { atomicOr(&st->flags, 1u); continue; }
             int bad = 0;
             if (k >= nfrec) {
                 int64_t x;
-                bool ok = len <= 16 && fast_atoi16(tw, len, &x);
+                bool ok = len <= 16 && fast_atoi16(tw, len, &x, bound);
                 if (!ok) {
                     if (len > 16) { len = 16; while (pos + len < kTextRegion && region[pos + len] != sep && region[pos + len] != '\n') ++len; }
                     ok = text_atoi(region + pos, len, &x);
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
                 else bad = kTextErrInt;
             } else {
                 double x;
-                int rc = len <= 16 ? fast_atof16(tw, len, s_p10, &x) : 1;
+                int rc = len <= 16 ? fast_atof16(tw, len, s_p10, &x, bound) : 1;
                 if (rc != 0) {
                     if (len > 16) { len = 16; while (pos + len < kTextRegion && region[pos + len] != sep && region[pos + len] != '\n') ++len; }
                     rc = text_atof(region + pos, len, &x);

@@ -115,13 +115,14 @@ MNW_TN int text_atof(const uint8_t* p, int len, double* out) {
 // value, host list and error.  Sixteen digits cannot overflow an int64 or exceed the 19 digits text_atof keeps.
 MNW_TN uint32_t tok_byte(const uint32_t (&w)[4], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
 
-MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out) {
+MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out, int bound = 16) {   // bound: >= len, the same in every lane
     const uint32_t c0 = w[0] & 0xffu;
     const bool sgn = c0 == '+' || c0 == '-', neg = c0 == '-';
     uint64_t v = 0;
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        if (i >= bound) break;
         const uint32_t d = tok_byte(w, i) - '0';
         const bool act = i < len && !(i == 0 && sgn);
         bad |= act && d > 9u;
@@ -132,7 +133,7 @@ MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out) {
     return true;
 }
 
-MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, double* out) {
+MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, double* out, int bound = 16) {
     const uint32_t c0 = w[0] & 0xffu;
     const bool sgn = c0 == '+' || c0 == '-', neg = c0 == '-';
     uint64_t m = 0;
@@ -140,6 +141,7 @@ MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, doubl
     bool seen_dot = false, seen_digit = false, in_exp = false, eneg = false, exp_digit = false, bad = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        if (i >= bound) break;
         const uint32_t c = tok_byte(w, i), d = c - '0';
         const bool isd = d <= 9u;
         const bool act = i < len && !(i == 0 && sgn);
