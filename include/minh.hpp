@@ -115,13 +115,27 @@ class Writer {
         mnw_ctx* ctx = minnow::detail::ctx();
 
         // ---- every codec column of the block is one job of one batch --------------------------------------
-        const size_t slot = detail::align16((size_t)8 * (size_t)N + 16);
-        size_t ncodec = 0, stage = 0;
-        for (const Column& c : cols_) if (!detail::isFixed(c.Type)) { ++ncodec; stage += detail::align16((size_t)N * (c.Type == Int ? 8 : 4)); }
-        uint8_t* dstreams = ncodec ? streams_.get(slot * ncodec) : nullptr;
-        uint8_t* dstage = (ncodec && !onDevice) ? stage_.get(stage + 16) : nullptr;
         std::vector<mnw_enc_job> jobs;
-        std::vector<mnw_block_meta> meta(ncodec);
+        std::vector<mnw_block_meta> meta;
+        std::vector<size_t> slotAt, slotCap;
+        uint8_t* dstreams = nullptr;
+        for (bool forceWide = false;; forceWide = true) {
+        jobs.clear(); slotAt.clear(); slotCap.clear();
+        // a column's stream slot holds the widest stream it can produce: 64 bits per element for an int column; a float
+        // column's pixel indices stay below `pixels`, so 32 bits when that is below 2^32 (it is for every real column)
+        size_t ncodec = 0, stage = 0, streamBytes = 0;
+        for (const Column& c : cols_) {
+            if (detail::isFixed(c.Type)) continue;
+            const bool wide = forceWide || c.Type == Int || (uint64_t)mnw_float_group_pixels(c.Low, c.High, c.Dx) >= (1ull << 32);
+            slotAt.push_back(streamBytes);
+            slotCap.push_back(detail::align16((size_t)(wide ? 8 : 4) * (size_t)N + 16));
+            streamBytes += slotCap.back();
+            ++ncodec;
+            stage += detail::align16((size_t)N * (c.Type == Int ? 8 : 4));
+        }
+        dstreams = ncodec ? streams_.get(streamBytes) : nullptr;
+        uint8_t* dstage = (ncodec && !onDevice) ? stage_.get(stage + 16) : nullptr;
+        meta.assign(ncodec, mnw_block_meta());
         size_t soff = 0;
         for (size_t i = 0; i < cols_.size(); ++i) {
             const Column& c = cols_[i];
@@ -136,9 +150,9 @@ class Writer {
             mnw_enc_job j;
             std::memset(&j, 0, sizeof j);
             j.src = src;
-            j.dst = dstreams + jobs.size() * slot;
+            j.dst = dstreams + slotAt[jobs.size()];
             j.n = N;
-            j.cap = (int64_t)slot;
+            j.cap = (int64_t)slotCap[jobs.size()];
             if (c.Type == Int) {
                 j.kind = MNW_INT_GROUP;
             } else {
@@ -150,7 +164,14 @@ class Writer {
             }
             jobs.push_back(j);
         }
-        if (!jobs.empty()) minnow::detail::check(mnw_encode_blocks(ctx, nullptr, jobs.data(), (int)jobs.size(), meta.data()));
+        if (jobs.empty()) break;
+        const int rc = mnw_encode_blocks(ctx, nullptr, jobs.data(), (int)jobs.size(), meta.data());
+        // a NaN in a float column quantizes to MinInt64 (amd64) and the block then needs up to 64 bits per element, as it
+        // does in the reference: encode once more with slots of that size
+        if (rc == MNW_E_CAPACITY && !forceWide) continue;
+        minnow::detail::check(rc);
+        break;
+        }
 
         // ---- the file, column after column as the reference writes it: one group per (block, column) ------------
         size_t k = 0;
@@ -172,7 +193,7 @@ class Writer {
             else f_->FloatGroup(N, c.Low, c.High, c.Dx);
             const mnw_block_meta& m = meta[k];
             host_.resize((size_t)m.nbytes);
-            minnow::detail::check(mnw_copy_to_host(ctx, host_.data(), dstreams + k * slot, m.nbytes));
+            minnow::detail::check(mnw_copy_to_host(ctx, host_.data(), dstreams + slotAt[k], m.nbytes));
             f_->DataEncoded(host_.data(), (size_t)m.nbytes, m.min, m.bits);
             ++k;
         }

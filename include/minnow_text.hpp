@@ -49,8 +49,7 @@ class Reader {
     }
     ~Reader() {
         Close();
-        mnw_ctx* ctx = minnow::detail::ctx();
-        for (void* p : dev_) if (p) mnw_dev_free(ctx, p);
+        if (dev_) mnw_dev_free(minnow::detail::ctx(), dev_);
     }
     Reader(const Reader&) = delete;
     Reader& operator=(const Reader&) = delete;
@@ -99,21 +98,21 @@ class Reader {
             const int idx = nameIndex(names[i]);
             if (isInt[i]) { iIdx.push_back(idx); iAt.push_back(i); } else { fIdx.push_back(idx); fAt.push_back(i); }
         }
-        // expandGeneric, text.go:192: every output gets len(lines) elements
-        if (dev_.size() < names.size()) { dev_.resize(names.size(), nullptr); cap_.resize(names.size(), 0); }
+        // expandGeneric, text.go:192: every output gets len(lines) elements -- one grow-only slab on the device, cut into columns
         BlockColumns out;
         out.rows = rows;
         out.ptr.resize(names.size());
-        for (size_t i = 0; i < names.size(); ++i) {
-            const size_t need = (size_t)rows * (isInt[i] ? 8 : 4) + 16;
-            if (cap_[i] < need) {
-                if (dev_[i]) minnow::detail::check(mnw_dev_free(ctx, dev_[i]));
-                dev_[i] = nullptr; cap_[i] = 0;
-                minnow::detail::check(mnw_dev_alloc(ctx, (int64_t)(need + need / 4), &dev_[i]));
-                cap_[i] = need + need / 4;
-            }
-            out.ptr[i] = dev_[i];
+        std::vector<size_t> at(names.size());
+        size_t need = 0;
+        for (size_t i = 0; i < names.size(); ++i) { at[i] = need; need += ((size_t)rows * (isInt[i] ? 8 : 4) + 255) & ~(size_t)255; }
+        if (cap_ < need + 256) {
+            if (dev_) minnow::detail::check(mnw_dev_free(ctx, dev_));
+            dev_ = nullptr; cap_ = 0;
+            const size_t want = need + need / 4 + 256;
+            minnow::detail::check(mnw_dev_alloc(ctx, (int64_t)want, &dev_));
+            cap_ = want;
         }
+        for (size_t i = 0; i < names.size(); ++i) out.ptr[i] = static_cast<uint8_t*>(dev_) + at[i];
         // at most 48 columns of each type per call of the C ABI
         size_t f0 = 0, i0 = 0;
         do {
@@ -201,8 +200,8 @@ class Reader {
     std::vector<int64_t> blockStarts_, blockSizes_;
     std::vector<std::string> names_;
     bool haveNames_ = false;
-    std::vector<void*> dev_;
-    std::vector<size_t> cap_;
+    void* dev_ = nullptr;            // the columns of the last Block
+    size_t cap_ = 0;
 };
 inline std::unique_ptr<Reader> Open(const std::string& fname, ReaderConfig config = ReaderConfig()) { return std::make_unique<Reader>(fname, config); }
 

@@ -1401,7 +1401,13 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             }
             p = e + 1;
         }
-        if (words < 0) return MNW_OK;                               // nothing but comments and blank lines
+        if (words < 0) {                                            // nothing but comments and blank lines
+            int64_t nl = 1;
+            for (int64_t q = 0; q < nbytes; ++q) nl += text[q] == '\n';
+            c->text_stats[0] = nl; c->text_stats[1] = 0; c->text_stats[2] = 0;
+            c->text_res = nullptr;
+            return MNW_OK;
+        }
         cols.fields_expected = words;
         if (cols.max_field >= words) {
             char buf[160];

@@ -183,6 +183,29 @@ static void TestLargeBlocks() {
     rd->Close();
 }
 
+// a NaN survives processFloatGroup (both comparisons are false), quantizes to MinInt64 on amd64 and makes the block 64 bits wide:
+// the writer must then take its wide stream slots, from host and from device arrays alike
+static void TestNaNBlock() {
+    const std::vector<Column> columns = {col(Int64), col(Float32), col(Int), col(Float, 0, 0, 250, 0.001f), col(Float, 1, 8, 16, 0.01f)};
+    Blocks blk;
+    const size_t n = 5000;
+    std::vector<int64_t> a(n, 7), c(n, 9);
+    std::vector<float> b(n, 1.5f), d(n), e(n, 1e10f);
+    for (size_t i = 0; i < n; ++i) d[i] = (float)(i % 250);
+    d[1234] = std::nanf("");
+    blk.i64 = {a}; blk.f32 = {b}; blk.in = {c}; blk.fl = {d}; blk.lg = {e};
+    const std::string fh = scratch + "/nan_host.minh", fd = scratch + "/nan_dev.minh";
+    writeFile(fh, columns, blk, false);
+    writeFile(fd, columns, blk, true);
+    const auto hb = slurp(fh);
+    EXPECT(hb == slurp(fd) && hb.size() > 8 * n, "NaN block: host-array and device-array writers disagree or the block is not wide");
+    auto rd = Open(fh);
+    std::vector<int64_t> in(n);
+    rd->IntBlock(0, {{"int", in.data()}});
+    EXPECT(in == c, "NaN block: the other columns are intact");
+    rd->Close();
+}
+
 // the reference panics (minh.go:100-103, 283-293, 329-334)
 static void TestPanics() {
     const std::string fname = scratch + "/panics.minh";
@@ -220,12 +243,13 @@ int main(int argc, char** argv) {
         TestReaderWriter();
         TestGoldenFile();
         TestLargeBlocks();
+        TestNaNBlock();
         TestPanics();
     } catch (const std::exception& e) {
         std::cerr << "EXCEPTION: " << e.what() << "\n";
         return 1;
     }
     if (failures) { std::cerr << failures << " failure(s)\n"; return 1; }
-    std::cout << "ok: 4 minh host tests\n";
+    std::cout << "ok: 5 minh host tests\n";
     return 0;
 }

@@ -206,3 +206,27 @@ def test_reference_panics_become_errors(mnw, torch_mod):
         assert "column 5 was requested" in str(e.value)
         n, fo, io = _parse(mnw, torch_mod, c, b"# only comments\n\n   \n", ord(" "), ord("#"), [0], [])
         assert n == 0
+
+
+def test_text_rows_then_parse(mnw, oracle, torch_mod):
+    """mnw_text_rows = the first half of the parse (lines, lines kept: what the reference sizes its outputs with, text.go:192);
+    the parse that follows reuses its upload, a parse of ANOTHER buffer of the same length does not"""
+    rng = np.random.default_rng(5)
+    with mnw.Context(0) as c:
+        def make(seed):
+            r = np.random.default_rng(seed)
+            rows = ["%07d %9.4f" % (int(r.integers(0, 10**7)), r.uniform(0, 9999)) for _ in range(3000)]
+            rows[100] = "# a comment line of the same length"[:17]
+            rows[200] = " " * 17
+            return ("\n".join(rows) + "\n").encode()
+        a, b = make(1), make(2)
+        assert len(a) == len(b) and a != b
+        for data in (a, b, b"# nothing\n\n", b"1 2\n"):
+            lines, kept = c.text_rows(data, ord(" "), ord("#"))
+            rf, ri = oracle.text_block_parse(data, ord(" "), ord("#"), [1], [0])
+            assert lines == data.count(b"\n") + 1 and kept == ri[0].size
+            n = _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0])
+            assert n == kept and c.text_stats()[:2] == (lines, kept)
+        c.text_rows(a, ord(" "), ord("#"))                       # rows of a, then a parse of b (same length, other bytes, other object)
+        _check(mnw, torch_mod, c, oracle, b, ord(" "), ord("#"), [1], [0])
+        _check(mnw, torch_mod, c, oracle, a, ord(" "), ord("#"), [1], [0])

@@ -157,7 +157,8 @@ int main(int argc, char** argv) {
         fM->Header(names, header, cols);
         fM->Geometry(L, 0, 0);
         std::vector<void*> cut(names.size(), nullptr);
-        std::vector<size_t> cutCap(names.size(), 0);
+        void* cutSlab = nullptr;
+        size_t cutCap = 0;
         double tParse = 0, tCut = 0, tWrite = 0;
         int64_t rowsIn = 0, rowsKept = 0, bytesIn = 0;
         for (int b = 0; b < fR->Blocks(); ++b) {
@@ -166,13 +167,17 @@ int main(int argc, char** argv) {
             tParse += now() - t; t = now();
             rowsIn += bc.rows; bytesIn += fR->BlockSize(b);
             std::vector<mnw_cut_col> cc(names.size());
+            size_t need = 0;
+            std::vector<size_t> at(names.size());
+            for (size_t i = 0; i < names.size(); ++i) { at[i] = need; need += ((size_t)bc.rows * (isInt[i] ? 8 : 4) + 255) & ~(size_t)255; }
+            if (cutCap < need + 256) {                            // one grow-only slab for the filtered columns
+                if (cutSlab) mnw_dev_free(ctx, cutSlab);
+                cutSlab = nullptr; cutCap = 0;
+                minnow::detail::check(mnw_dev_alloc(ctx, (int64_t)(need + need / 4 + 256), &cutSlab));
+                cutCap = need + need / 4 + 256;
+            }
             for (size_t i = 0; i < names.size(); ++i) {
-                const size_t need = (size_t)bc.rows * (isInt[i] ? 8 : 4) + 16;
-                if (cutCap[i] < need) {
-                    if (cut[i]) mnw_dev_free(ctx, cut[i]);
-                    minnow::detail::check(mnw_dev_alloc(ctx, (int64_t)(need + need / 4), &cut[i]));
-                    cutCap[i] = need + need / 4;
-                }
+                cut[i] = static_cast<uint8_t*>(cutSlab) + at[i];
                 cc[i].src = bc.ptr[i]; cc[i].dst = cut[i]; cc[i].elem_bytes = isInt[i] ? 8 : 4; cc[i].reserved = 0;
             }
             int64_t n = 0;                                        // GenericCut, text_to_minh.go:271-288
@@ -185,7 +190,7 @@ int main(int argc, char** argv) {
         fM->Close();
         fR->Close();
         const double total = now() - t0;
-        for (void* p : cut) if (p) mnw_dev_free(ctx, p);
+        if (cutSlab) mnw_dev_free(ctx, cutSlab);
         mnw_kernel_time kt[MNW_K_COUNT];
         mnw_timing_get(ctx, kt);
         double kms = 0;
