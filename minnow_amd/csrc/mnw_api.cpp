@@ -9,6 +9,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <errno.h>
+#include <ctype.h>
 
 #include <string>
 #include <vector>
@@ -1408,7 +1409,7 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             c->text_res = nullptr;
             return MNW_OK;
         }
-        cols.fields_expected = words;
+        cols.fields_expected = (n_float + n_int) > 0 ? words : -1;   // parseInt64s / parseFloat32s return at once when they have no column (parse.go:83, 132)
         if (cols.max_field >= words) {
             char buf[160];
             snprintf(buf, sizeof buf, "Data has %d columns, but column %d was requested.", words, cols.max_field);    // parse.go:98-103
@@ -1459,7 +1460,10 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             char* endp = nullptr;
             errno = 0;
             const double v = strtod(tok.c_str(), &endp);
-            if (endp != tok.c_str() + tok.size() || tok.find('_') != std::string::npos) {
+            // ... but strtod also takes a hex mantissa without the 'p' exponent that ParseFloat insists on, and white space in front
+            const bool hex = tok.find('x') != std::string::npos || tok.find('X') != std::string::npos;
+            const bool hex_no_p = hex && tok.find('p') == std::string::npos && tok.find('P') == std::string::npos;
+            if (endp != tok.c_str() + tok.size() || tok.find('_') != std::string::npos || hex_no_p || isspace((unsigned char)tok[0])) {
                 char buf[200];
                 snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": invalid syntax", tok.c_str());
                 return fail(c, MNW_E_DOMAIN, buf);

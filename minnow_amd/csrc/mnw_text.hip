@@ -16,10 +16,10 @@
 //                  into a table in LDS, [column][line], and the fields are converted ONE FIELD PER THREAD in table order:
 //                  the lanes stay busy whatever the lines look like, neighbouring lanes convert neighbouring rows of one
 //                  column -- the same code path, stores into the same lines -- and a token is converted out of four
-//                  registers holding its first 16 bytes, without loops or branches.
-//                  A tile that holds a comment character, a line that does not end inside the staged text, more than
-//                  2,048 kept lines or more wanted fields than the table holds takes the general path: one thread per
-//                  line, walking it byte by byte as the reference does.
+//                  registers holding its first 16 bytes, in straight-line code as long as the wave's longest token.
+//                  A tile that holds a comment character, a line that does not end inside the staged text or more wanted
+//                  fields than the table holds (6,144) takes the general path: one thread per line, walking it byte by
+//                  byte as the reference does.
 //
 // Numbers: a decimal literal whose digits fit 2^53 and whose power of ten is within 10^+-22 is converted with ONE
 // correctly rounded float64 multiplication or division of two exactly representable values (Clinger's fast path), so
@@ -32,7 +32,6 @@ constexpr int kTextTile = 12288;          // bytes of text whose line starts one
 constexpr int kTextRegion = 16384;        // bytes a workgroup stages: 256 threads x 64
 constexpr int kTextLead = 16;             // staged bytes in front of the tile (the byte before the tile decides whether a line starts at its first byte)
 constexpr int kTextRecCap = 6144;         // wanted fields per tile on the fast path (kept lines x wanted columns)
-constexpr int kTextMaxRowOff = 2048;      // kept lines per tile on the fast path
 constexpr int kTextMaxCols = 256;         // fields per line that can be addressed
 constexpr int kTextMaxOut = 48;           // requested columns of each type
 
@@ -40,7 +39,7 @@ struct TextCols {
     int16_t slot[kTextMaxCols];           // field -> -1 (not wanted) | output column: 0 .. n_float-1 float32, n_float .. n_float+n_int-1 int64
     void* out[2 * kTextMaxOut];           // output column -> device array
     int32_t n_float, n_int;
-    int32_t fields_expected;              // every line must have this many fields (parse.go:96-103)
+    int32_t fields_expected;              // every line must have this many fields (parse.go:96-118); -1: no column is wanted, nothing is checked (parse.go:83)
     int32_t max_field;                    // highest wanted field: the rest of the line is only counted
 };
 
@@ -302,13 +301,13 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
                 const int l = nl_before + j;                       // the line this newline ends was started by counted newline l - 1
                 if (l >= 1 && l <= nown && cnt > 0) {
                     validend |= 1ull << b;
-                    if (cnt != cols.fields_expected) text_error(st, line_base + l - 1, kTextErrFields);     // parse.go:114-118
+                    if (cols.fields_expected >= 0 && cnt != cols.fields_expected) text_error(st, line_base + l - 1, kTextErrFields);     // parse.go:114-118
                 }
                 cnt_in = 0; prev = b; ++j;
             }
         }
         const int vbase = block_exclusive_scan(__popcll(validend), wsum, &vtotal);
-        if (vtotal > kTextMaxRowOff || vtotal * n_want > kTextRecCap) general = true;
+        if (vtotal * n_want > kTextRecCap) general = true;
         else {
             uint64_t m = start;
             while (m) {
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
             }
             ++field;
         }
-        if (field != cols.fields_expected) text_error(st, line, kTextErrFields);
+        if (cols.fields_expected >= 0 && field != cols.fields_expected) text_error(st, line, kTextErrFields);
         ++row;
     }
 }

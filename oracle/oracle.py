@@ -9,6 +9,8 @@ import ctypes as C
 import os
 import subprocess
 
+import math
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -377,15 +379,26 @@ def text_block_parse(data, sep, comm, float_cols, int_cols):
     want = list(float_cols) + list(int_cols)
     if want and max(want) >= buf_len:
         raise ValueError("Data has %d columns, but column %d was requested." % (buf_len, max(want)))
+    if not want:                                        # parseInt64s / parseFloat32s return at once without columns (parse.go:83, 132)
+        return fout, iout
     for i, ln in enumerate(lines):
         words = [w for w in ln.split(sep_b) if w != b""]
         if len(words) != buf_len:
             raise ValueError("Data on line %d has %d columns, not %d." % (i + 1, len(words), buf_len))
         for k, c in enumerate(float_cols):
+            tok = words[c].decode("ascii")
+            if "_" in tok or tok != tok.strip():                  # Python's float() takes digit separators and white space; ParseFloat does not
+                raise ValueError("strconv.ParseFloat: parsing %r: invalid syntax" % tok)
+            x = float(tok)
+            if math.isinf(x) and "n" not in tok.lower():          # ErrRange, which the reference panics on ("inf" / "infinity" are values)
+                raise ValueError("strconv.ParseFloat: parsing %r: value out of range" % tok)
             with np.errstate(over="ignore"):                       # float32(x) beyond float32's range is +-Inf in Go too
-                fout[k][i] = np.float32(float(words[c].decode("ascii")))
+                fout[k][i] = np.float32(x)
         for k, c in enumerate(int_cols):
-            v = int(words[c].decode("ascii"))
+            tok = words[c].decode("ascii")
+            if "_" in tok or tok != tok.strip():                  # as above: Atoi takes neither
+                raise ValueError("strconv.Atoi: parsing %r: invalid syntax" % tok)
+            v = int(tok)
             if not -2**63 <= v < 2**63:
                 raise ValueError("strconv.Atoi: value out of range")
             iout[k][i] = v

@@ -230,3 +230,12 @@ def test_text_rows_then_parse(mnw, oracle, torch_mod):
         c.text_rows(a, ord(" "), ord("#"))                       # rows of a, then a parse of b (same length, other bytes, other object)
         _check(mnw, torch_mod, c, oracle, b, ord(" "), ord("#"), [1], [0])
         _check(mnw, torch_mod, c, oracle, a, ord(" "), ord("#"), [1], [0])
+
+
+def test_randomised_differential_short(mnw, oracle, torch_mod):
+    """a short seeded leg of tests/fuzz_text.py: random well-formed and malformed catalogues, library against oracle"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_text
+    n, errors, general = fuzz_text.run(cases=250, seed=20261004)
+    assert n == 250 and errors > 10 and general > 10
