@@ -2,9 +2,9 @@
 """BASELINE configs[4] shape on one GPU: text_to_minh of a Rockstar-style catalogue, end to end (text file -> .minh file),
 and the read back.  ROWS rows of 44 columns (4 ids, 20 logarithmic, 10 positions, 10 velocities) are written to a
 scratch file; tools/text_to_minh (C++ over include/minnow_text.hpp + minh.hpp) converts it with the reference's loop
-(Block -> GenericCut -> minh.Block); the oracle's restatement of text.Reader.Block is timed on a bounded sample beside
-it.  Prints one JSON object."""
-import json, os, subprocess, sys, tempfile, time
+(Block -> GenericCut -> minh.Block), then reads every column back into device arrays.  Prints one JSON object.
+(No CPU figure here: the oracle is test infrastructure; only tests/, smoke() and bench.py's cpu_baseline leg may run it.)"""
+import json, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -53,15 +53,7 @@ for rep in range(3):                                    # the file is in the pag
 rb = subprocess.run([exe, "--read", out], capture_output=True, text=True, timeout=1200)
 assert rb.returncode == 0, rb.stdout + rb.stderr
 best["read_back"] = json.loads(rb.stdout)
-# the oracle (pure Python restatement of parse.go) on a bounded sample of the same text, one core
-from oracle import oracle
-sample = data[:data.index(b"\n", 6_000_000) + 1]
-t = time.perf_counter()
-oracle.text_block_parse(sample, ord(" "), ord("#"), list(range(4, 44)), list(range(4)))
-dt = time.perf_counter() - t
-best.update({"rows_generated": rows, "columns": 44, "bytes_per_row": len(data) / rows, "max_block_bytes": max_block,
-             "cpu_parse_baseline": {"value": len(sample) / dt / 1e9, "unit": "GB/s of text", "cores": 1, "kind": "port",
-                                    "sample": "%d bytes of the same text through the oracle's Python restatement of text.Reader.Block" % len(sample)}})
+best.update({"rows_generated": rows, "columns": 44, "bytes_per_row": len(data) / rows, "max_block_bytes": max_block})
 print(json.dumps(best))
 for f in (src, out):
     os.remove(f)
