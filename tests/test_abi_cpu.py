@@ -54,9 +54,9 @@ def test_struct_layouts_match_header(mnw):
 #include <stddef.h>
 #include "minnow_hip.h"
 int main(void) {
-    printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mnw_enc_job), offsetof(mnw_enc_job, xform), sizeof(mnw_dec_job),
+    printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(mnw_enc_job), offsetof(mnw_enc_job, xform), sizeof(mnw_dec_job),
            offsetof(mnw_dec_job, xform), sizeof(mnw_block_meta), sizeof(mnw_kernel_time), sizeof(mnw_minh_col),
-           offsetof(mnw_minh_col, log));
+           offsetof(mnw_minh_col, log), sizeof(mnw_cut_col), offsetof(mnw_cut_col, elem_bytes));
     return 0;
 }
 """
@@ -66,7 +66,8 @@ int main(void) {
         subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     want = [C.sizeof(_lib.EncJobC), _lib.EncJobC.xform.offset, C.sizeof(_lib.DecJobC), _lib.DecJobC.xform.offset,
-            C.sizeof(_lib.BlockMetaC), C.sizeof(_lib.KernelTimeC), C.sizeof(_lib.MinhColC), _lib.MinhColC.log.offset]
+            C.sizeof(_lib.BlockMetaC), C.sizeof(_lib.KernelTimeC), C.sizeof(_lib.MinhColC), _lib.MinhColC.log.offset,
+            C.sizeof(_lib.CutColC), _lib.CutColC.elem_bytes.offset]
     assert got == want
 
 
@@ -96,12 +97,13 @@ def test_no_gpu_fails_loudly(mnw):
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under minnow_amd/ or include/ may reference it."""
+    """The oracle is test infrastructure: nothing under minnow_amd/, include/ or tools/ may reference it (only tests/,
+    smoke() and bench.py's cpu_baseline leg do)."""
     bad = []
-    for base in ("minnow_amd", "include"):
+    for base in ("minnow_amd", "include", "tools"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".sh")):
                     txt = open(os.path.join(dirpath, f), errors="ignore").read()
                     if re.search(r"mnw_oracle|mnwo_|from oracle|import oracle|oracle/", txt.replace("never includes anything from oracle/", "")):
                         bad.append(os.path.join(dirpath, f))
