@@ -15,13 +15,15 @@ BIN = os.path.join(ROOT, "tests", "cpp", "test_minnow_host")
 
 MINH_SRC = os.path.join(ROOT, "tests", "cpp", "test_minh_host.cpp")
 MINH_BIN = os.path.join(ROOT, "tests", "cpp", "test_minh_host")
+MINP_SRC = os.path.join(ROOT, "tests", "cpp", "test_minp_host.cpp")
+MINP_BIN = os.path.join(ROOT, "tests", "cpp", "test_minp_host")
 
 
 def _build(src=SRC, exe=BIN):
     from minnow_amd import build as b
     b.build()
     lib_dir = os.path.join(ROOT, "minnow_amd")
-    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("minnow.hpp", "minh.hpp", "minnow_hip.h")] + [b.LIB]
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("minnow.hpp", "minh.hpp", "minp.hpp", "minnow_hip.h")] + [b.LIB]
     if (not os.path.exists(exe)) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L", lib_dir, "-lminnow_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
@@ -34,6 +36,8 @@ def test_host_header_compiles_and_links():
     assert os.path.exists(BIN)
     _build(MINH_SRC, MINH_BIN)
     assert os.path.exists(MINH_BIN)
+    _build(MINP_SRC, MINP_BIN)
+    assert os.path.exists(MINP_BIN)
 
 
 @pytest.mark.gpu
@@ -66,3 +70,15 @@ def test_cpp_minh_host_tests_on_gpu(tmp_path):
     r = subprocess.run([exe, str(scratch), str(gold)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok: 5 minh host tests" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_minp_host_tests_on_gpu(tmp_path):
+    """include/minp.hpp: the reference's TestVecReaderWriter and TestIDs (go/minp/minp_test.go:7-100); the file written from
+    the whole grid on the device equals, byte for byte, the one written block by block through getSubCell; device grids"""
+    exe = _build(MINP_SRC, MINP_BIN)
+    scratch = tmp_path / "test_files"
+    scratch.mkdir()
+    r = subprocess.run([exe, str(scratch)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: 3 minp host tests" in r.stdout
