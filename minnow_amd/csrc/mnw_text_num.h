@@ -122,11 +122,12 @@ MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out, int bound
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (i >= bound) break;
-        const uint32_t d = tok_byte(w, i) - '0';
-        const bool act = i < len && !(i == 0 && sgn);
-        bad |= act && d > 9u;
-        v = act ? v * 10 + d : v;
+        if (i < bound) {                                   // (a wave-uniform test; no break, so that the loop unrolls)
+            const uint32_t d = tok_byte(w, i) - '0';
+            const bool act = i < len && !(i == 0 && sgn);
+            bad |= act && d > 9u;
+            v = act ? v * 10 + d : v;
+        }
     }
     if (bad || len - (sgn ? 1 : 0) <= 0) return false;
     *out = neg ? (int64_t)(0 - v) : (int64_t)v;
@@ -141,23 +142,24 @@ MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, doubl
     bool seen_dot = false, seen_digit = false, in_exp = false, eneg = false, exp_digit = false, bad = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (i >= bound) break;
-        const uint32_t c = tok_byte(w, i), d = c - '0';
-        const bool isd = d <= 9u;
-        const bool act = i < len && !(i == 0 && sgn);
-        const bool mant = act && !in_exp, expo = act && in_exp;
-        const bool is_dot = c == '.' && !seen_dot, is_e = (c | 0x20u) == 'e' && seen_digit;
-        const bool is_esign = i == exp_pos + 1 && (c == '+' || c == '-');
-        bad |= (mant && !isd && !is_dot && !is_e) || (expo && !isd && !is_esign);
-        // exponent part first: it tests in_exp as it was before this character
-        ex = (expo && isd) ? (ex > 99999 ? ex : ex * 10 + (int)d) : ex;
-        exp_digit |= expo && isd;
-        eneg |= expo && is_esign && c == '-';
-        m = (mant && isd) ? m * 10 + d : m;
-        e10 -= (mant && isd && seen_dot) ? 1 : 0;
-        seen_digit |= mant && isd;
-        if (mant && !isd && is_e) { in_exp = true; exp_pos = i; }
-        seen_dot |= mant && !isd && is_dot;
+        if (i < bound) {
+            const uint32_t c = tok_byte(w, i), d = c - '0';
+            const bool isd = d <= 9u;
+            const bool act = i < len && !(i == 0 && sgn);
+            const bool mant = act && !in_exp, expo = act && in_exp;
+            const bool is_dot = c == '.' && !seen_dot, is_e = (c | 0x20u) == 'e' && seen_digit;
+            const bool is_esign = i == exp_pos + 1 && (c == '+' || c == '-');
+            bad |= (mant && !isd && !is_dot && !is_e) || (expo && !isd && !is_esign);
+            // exponent part first: it tests in_exp as it was before this character
+            ex = (expo && isd) ? (ex > 99999 ? ex : ex * 10 + (int)d) : ex;
+            exp_digit |= expo && isd;
+            eneg |= expo && is_esign && c == '-';
+            m = (mant && isd) ? m * 10 + d : m;
+            e10 -= (mant && isd && seen_dot) ? 1 : 0;
+            seen_digit |= mant && isd;
+            if (mant && !isd && is_e) { in_exp = true; exp_pos = i; }
+            seen_dot |= mant && !isd && is_dot;
+        }
     }
     if (bad || !seen_digit || (in_exp && !exp_digit)) return 1;
     e10 += eneg ? -ex : ex;
