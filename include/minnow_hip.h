@@ -229,7 +229,7 @@ int mnw_minh_selftest(mnw_ctx *ctx, int which, uint64_t first, uint64_t count, u
  * is broken into fields at runs of `sep`, and the requested fields are converted: int columns with strconv.Atoi,
  * float columns with float32(strconv.ParseFloat(s, 64)).  text is a HOST buffer (the reader's rd.buf); the outputs
  * are DEVICE arrays of `capacity_rows` elements each, ready to be handed to mnw_encode_blocks: float_out[k] receives
- * field float_cols[k], int_out[k] field int_cols[k] (0-based field numbers, at most 48 of each, fields < 256).
+ * field float_cols[k], int_out[k] field int_cols[k] (0-based field numbers, at most 128 columns in all, fields < 256).
  * *n_rows = lines kept.  Every kept line must have as many fields as the first kept line has whitespace-separated
  * words (parse.go:96-103); a line that does not, or a field that Atoi / ParseFloat would reject, gives MNW_E_DOMAIN
  * (the reference panics) with the line in mnw_last_error.  Synchronous. */

@@ -113,10 +113,10 @@ class Reader {
             cap_ = want;
         }
         for (size_t i = 0; i < names.size(); ++i) out.ptr[i] = static_cast<uint8_t*>(dev_) + at[i];
-        // at most 48 columns of each type per call of the C ABI
+        // at most 128 columns per call of the C ABI
         size_t f0 = 0, i0 = 0;
         do {
-            const size_t nf = std::min<size_t>(48, fIdx.size() - f0), ni = std::min<size_t>(48, iIdx.size() - i0);
+            const size_t nf = std::min<size_t>(128, fIdx.size() - f0), ni = std::min<size_t>(128 - nf, iIdx.size() - i0);
             std::vector<float*> fo(nf);
             std::vector<int64_t*> io(ni);
             for (size_t k = 0; k < nf; ++k) fo[k] = static_cast<float*>(out.ptr[fAt[f0 + k]]);

@@ -44,8 +44,8 @@ struct MinhArgs { MinhCol col[kMinhBatch]; };
 void launch_minh_process(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_unlog(hipStream_t, int, const MinhArgs&, int, int64_t);
 void launch_minh_selftest(hipStream_t, int, uint64_t, uint64_t, unsigned long long*);
-constexpr int kTextTile = 12288, kTextMaxCols = 256, kTextMaxOut = 48;
-struct TextCols { int16_t slot[kTextMaxCols]; void* out[2 * kTextMaxOut]; int32_t n_float, n_int; int32_t fields_expected; int32_t max_field; };
+constexpr int kTextTile = 12288, kTextMaxCols = 256, kTextMaxOut = 128;
+struct TextCols { int16_t slot[kTextMaxCols]; void* out[kTextMaxOut]; int32_t n_float, n_int; int32_t fields_expected; int32_t max_field; };
 struct TextSlow { int64_t row; int64_t offset; int32_t len; int32_t slot; };
 struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned int flags; long long n_rows; long long n_lines; unsigned int tiles_general; unsigned int pad; };
 void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, int64_t*);
@@ -1363,7 +1363,7 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
                    const int32_t* float_cols, int n_float, float* const* float_out,
                    const int32_t* int_cols, int n_int, int64_t* const* int_out, int64_t capacity_rows, int64_t* n_rows) {
     if (!c || !n_rows || nbytes < 0 || n_float < 0 || n_int < 0 || (nbytes > 0 && !text)) return fail(c, MNW_E_ARG, "text: bad arguments");
-    if (n_float > mnw::kTextMaxOut || n_int > mnw::kTextMaxOut) return fail(c, MNW_E_ARG, "text: at most 48 columns of each type per call");
+    if (n_float + n_int > mnw::kTextMaxOut) return fail(c, MNW_E_ARG, "text: at most 128 columns per call");
     if ((n_float > 0 && (!float_cols || !float_out)) || (n_int > 0 && (!int_cols || !int_out))) return fail(c, MNW_E_ARG, "text: null column arrays");
     if (sep == '\n' || comment == '\n') return fail(c, MNW_E_ARG, "text: the newline cannot be the separator or the comment character");
     *n_rows = 0;

@@ -33,11 +33,11 @@ constexpr int kTextRegion = 16384;        // bytes a workgroup stages: 256 threa
 constexpr int kTextLead = 16;             // staged bytes in front of the tile (the byte before the tile decides whether a line starts at its first byte)
 constexpr int kTextRecCap = 6144;         // wanted fields per tile on the fast path (kept lines x wanted columns)
 constexpr int kTextMaxCols = 256;         // fields per line that can be addressed
-constexpr int kTextMaxOut = 48;           // requested columns of each type
+constexpr int kTextMaxOut = 128;          // requested columns per call, float32 and int64 together
 
 struct TextCols {
     int16_t slot[kTextMaxCols];           // field -> -1 (not wanted) | output column: 0 .. n_float-1 float32, n_float .. n_float+n_int-1 int64
-    void* out[2 * kTextMaxOut];           // output column -> device array
+    void* out[kTextMaxOut];               // output column -> device array
     int32_t n_float, n_int;
     int32_t fields_expected;              // every line must have this many fields (parse.go:96-118); -1: no column is wanted, nothing is checked (parse.go:83)
     int32_t max_field;                    // highest wanted field: the rest of the line is only counted
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
     __shared__ __attribute__((aligned(16))) uint8_t region[kTextRegion + 32];      // (+32: a token's 16-byte window may reach behind the end)
     __shared__ __attribute__((aligned(16))) uint16_t rec[kTextRecCap];      // rec[column * kept lines + line] = where the field starts
     __shared__ int16_t s_slot[kTextMaxCols];
-    __shared__ void* s_out[2 * kTextMaxOut];
+    __shared__ void* s_out[kTextMaxOut];
     __shared__ double s_p10[23];
     __shared__ int wsum[4];
     __shared__ uint32_t wseg[4];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_text_parse(const uint8_t* __restrict__ 
     const int64_t line_base = tile_base[2 * (int64_t)blockIdx.x], row_base = tile_base[2 * (int64_t)blockIdx.x + 1];
     if (t == 0) { s_flags = 0; s_nown = 0; }
     s_slot[t] = cols.slot[t];
-    if (t < 2 * kTextMaxOut) s_out[t] = cols.out[t];
+    if (t < kTextMaxOut) s_out[t] = cols.out[t];
     if (t < 23) s_p10[t] = text_pow10(t);
     if (t < 8) reinterpret_cast<uint32_t*>(region + kTextRegion)[t] = 0x0a0a0a0au;
     // every table entry starts out as "no such field": a line with too few fields (an error the host reports) leaves holes

@@ -208,6 +208,22 @@ def test_reference_panics_become_errors(mnw, torch_mod):
         assert n == 0
 
 
+def test_wide_catalogue_all_columns(mnw, oracle, torch_mod):
+    """120 columns, all of them requested in one call (the C ABI takes up to 128 columns per call); 129 is an argument error"""
+    rng = np.random.default_rng(8)
+    ncol = 120
+    rows = []
+    for r in range(700):
+        rows.append(" ".join(str(int(rng.integers(-10**9, 10**9))) if k % 2 else "%.4e" % (10 ** rng.uniform(-3, 12)) for k in range(ncol)))
+    data = ("\n".join(rows) + "\n").encode()
+    with mnw.Context(0) as c:
+        fcols, icols = list(range(0, ncol, 2)), list(range(1, ncol, 2))
+        assert _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), fcols, icols) == 700
+        assert c.text_stats()[2] == 0
+        with pytest.raises(mnw.MnwError):
+            _parse(mnw, torch_mod, c, b"1 2\n", ord(" "), ord("#"), list(range(65)), list(range(65, 129)))
+
+
 def test_text_rows_then_parse(mnw, oracle, torch_mod):
     """mnw_text_rows = the first half of the parse (lines, lines kept: what the reference sizes its outputs with, text.go:192);
     the parse that follows reuses its upload, a parse of ANOTHER buffer of the same length does not"""
