@@ -255,3 +255,34 @@ def test_randomised_differential_short(mnw, oracle, torch_mod):
     import fuzz_text
     n, errors, general = fuzz_text.run(cases=250, seed=20261004)
     assert n == 250 and errors > 10 and general > 10
+
+
+def test_block_beyond_4_gib(mnw, oracle, torch_mod):
+    """a block of more than 2^32 bytes (the reference's blocks go up to 5 GiB, text.go:35): offsets, line numbers and rows
+    past the 32-bit range.  The text is one chunk repeated, so the oracle only has to parse the chunk; a literal that only
+    the host path converts sits behind the 4 GiB mark."""
+    rng = np.random.default_rng(12)
+    lines = ["%d %.5f" % (int(rng.integers(0, 10**9)), rng.uniform(0, 250)) for _ in range(20000)]
+    chunk = ("\n".join(lines) + "\n").encode()
+    reps = (2**32 + 2**27) // len(chunk) + 1
+    special = b"7 0.12345678901234567890123\n"                      # more than 19 digits: the host's strtod converts it
+    data = chunk * (reps - 1) + special + chunk
+    assert len(data) > 2**32 + 2**26
+    rf, ri = oracle.text_block_parse(chunk, ord(" "), ord("#"), [1], [0])
+    nrows = 20000 * reps + 1
+    dev = torch_mod.device("cuda:0")
+    with mnw.Context(0) as c:
+        lines_n, kept = c.text_rows(data, ord(" "), ord("#"))
+        assert kept == nrows and lines_n == nrows + 1
+        fo = torch_mod.empty(nrows + 8, dtype=torch_mod.float32, device=dev)
+        io = torch_mod.empty(nrows + 8, dtype=torch_mod.int64, device=dev)
+        torch_mod.cuda.synchronize()
+        n = c.text_parse(data, ord(" "), ord("#"), [1], [fo.data_ptr()], [0], [io.data_ptr()], nrows + 8)
+        torch_mod.cuda.synchronize()
+        assert n == nrows and c.text_stats()[2] == 0
+        f, i = fo[:n].cpu().numpy(), io[:n].cpu().numpy()
+    at = 20000 * (reps - 1)
+    assert np.array_equal(f[:at].reshape(reps - 1, 20000).view(np.uint32), np.broadcast_to(rf[0].view(np.uint32), (reps - 1, 20000)))
+    assert np.array_equal(i[:at].reshape(reps - 1, 20000), np.broadcast_to(ri[0], (reps - 1, 20000)))
+    assert i[at] == 7 and f[at] == np.float32(0.12345678901234567890123)
+    assert np.array_equal(f[at + 1:].view(np.uint32), rf[0].view(np.uint32)) and np.array_equal(i[at + 1:], ri[0])
