@@ -1331,6 +1331,7 @@ int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint
     if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
     if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
     HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    if (c->timing) HIPCHK(c, hipStreamSynchronize(s));      // an event recorded behind a pageable copy is stamped before the copy has finished
     {
         ScopedTimer t(c, s, MNW_K_TEXT_LINES);
         mnw::launch_text_count(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (int64_t*)c->d_tile);

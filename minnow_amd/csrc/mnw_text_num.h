@@ -134,34 +134,64 @@ MNW_TN bool fast_atoi16(const uint32_t (&w)[4], int len, int64_t* out, int bound
     return true;
 }
 
+// 4 bits: which bytes of w equal the byte replicated in pat / which bytes are not a decimal digit (exact for all 256 byte values)
+MNW_TN uint32_t tok_eq4(uint32_t w, uint32_t pat) {
+    const uint32_t x = w ^ pat;
+    const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+    return (z * 0x00204081u) >> 28;
+}
+MNW_TN uint32_t tok_nondigit4(uint32_t w) {
+    const uint32_t x = w ^ 0x30303030u;                                   // '0'..'9' -> 0..9
+    const uint32_t t = (((x & 0x7f7f7f7fu) + 0x76767676u) | x) & 0x80808080u;   // high bit: the byte is above 9
+    return (t * 0x00204081u) >> 28;
+}
+
+// The token's structure -- sign, digits with at most one dot, optionally e / E, sign, digits -- is read off five 16-bit
+// masks made with byte-parallel compares; the loop over the characters then only accumulates digits: the mantissa where
+// the mantissa-digit mask has a bit, the exponent where the exponent-digit mask has one.
 MNW_TN int fast_atof16(const uint32_t (&w)[4], int len, const double* p10, double* out, int bound = 16) {
-    const uint32_t c0 = w[0] & 0xffu;
-    const bool sgn = c0 == '+' || c0 == '-', neg = c0 == '-';
+    uint32_t nd = 0, dot = 0, em = 0, plus = 0, minus = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        nd |= tok_nondigit4(w[q]) << (4 * q);
+        dot |= tok_eq4(w[q], 0x2e2e2e2eu) << (4 * q);
+        em |= tok_eq4(w[q] | 0x20202020u, 0x65656565u) << (4 * q);
+        plus |= tok_eq4(w[q], 0x2b2b2b2bu) << (4 * q);
+        minus |= tok_eq4(w[q], 0x2d2d2d2du) << (4 * q);
+    }
+    const uint32_t lenmask = len >= 16 ? 0xffffu : ((1u << len) - 1u);
+    const uint32_t sign = plus | minus;
+    const uint32_t s0 = sign & 1u;
+    const bool neg = (minus & 1u) != 0;
+    em &= lenmask & ~1u;
+    const int epos = em ? __builtin_ctz(em) : len;
+    const uint32_t below_e = (1u << epos) - 1u;
+    const uint32_t mant = below_e & lenmask & ~s0;                        // positions of the mantissa
+    const uint32_t dots = dot & mant;
+    const uint32_t mdig = ~nd & mant;                                     // its digits
+    const int dpos = dots ? __builtin_ctz(dots) : epos;
+    bool bad = (nd & mant) != dots || (dots & (dots - 1u)) != 0 || mdig == 0;
+    uint32_t edig = 0;
+    bool eneg = false;
+    if (epos < len) {
+        const uint32_t expo = lenmask & ~below_e & ~(1u << epos);         // positions behind the e
+        const uint32_t es = sign & (1u << (epos + 1)) & expo;             // a sign directly behind it
+        eneg = (minus & es) != 0;
+        edig = ~nd & expo;
+        bad = bad || (nd & expo) != es || edig == 0;
+    }
+    if (bad) return 1;
     uint64_t m = 0;
-    int e10 = 0, ex = 0, exp_pos = -2;
-    bool seen_dot = false, seen_digit = false, in_exp = false, eneg = false, exp_digit = false, bad = false;
+    int ex = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        if (i < bound) {
-            const uint32_t c = tok_byte(w, i), d = c - '0';
-            const bool isd = d <= 9u;
-            const bool act = i < len && !(i == 0 && sgn);
-            const bool mant = act && !in_exp, expo = act && in_exp;
-            const bool is_dot = c == '.' && !seen_dot, is_e = (c | 0x20u) == 'e' && seen_digit;
-            const bool is_esign = i == exp_pos + 1 && (c == '+' || c == '-');
-            bad |= (mant && !isd && !is_dot && !is_e) || (expo && !isd && !is_esign);
-            // exponent part first: it tests in_exp as it was before this character
-            ex = (expo && isd) ? (ex > 99999 ? ex : ex * 10 + (int)d) : ex;
-            exp_digit |= expo && isd;
-            eneg |= expo && is_esign && c == '-';
-            m = (mant && isd) ? m * 10 + d : m;
-            e10 -= (mant && isd && seen_dot) ? 1 : 0;
-            seen_digit |= mant && isd;
-            if (mant && !isd && is_e) { in_exp = true; exp_pos = i; }
-            seen_dot |= mant && !isd && is_dot;
+        if (i < bound) {                                   // (a wave-uniform test; no break, so that the loop unrolls)
+            const uint32_t d = tok_byte(w, i) - '0';
+            m = ((mdig >> i) & 1u) ? m * 10 + d : m;
+            ex = ((edig >> i) & 1u) ? (ex > 99999 ? ex : ex * 10 + (int)d) : ex;
         }
     }
-    if (bad || !seen_digit || (in_exp && !exp_digit)) return 1;
+    int e10 = -(int)__builtin_popcount(mdig & ~((2u << dpos) - 1u));      // mantissa digits behind the dot
     e10 += eneg ? -ex : ex;
     double v;
     if (m == 0) v = 0.0;

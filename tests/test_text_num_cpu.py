@@ -94,6 +94,15 @@ def test_float_literals(tn):
         k = int(rng.integers(0, len(s) + 1))
         n_value += _check_float(tn, s[:k] + "." + s[k:]) == 0
     assert n_value > 30000
+    # the register form must take the tokens catalogues are made of itself (giving up is correct but slow)
+    for fmt, scale in (("%.4e", 1e12), ("%.5f", 250.0), ("%.2f", 3000.0), ("%.6e", 1e-5), ("%d", 1e6), ("%.3E", 1e8)):
+        for v in rng.standard_normal(500) * scale:
+            tok = (fmt % v).encode()
+            y = C.c_double()
+            assert len(tok) <= 16 and tn.tn_fast_atof(tok, len(tok), C.byref(y)) == 0 and y.value == float(tok), tok
+    for tok in (b".5", b"5.", b"-.5e-3", b"+1E+05", b"0", b"-0.0", b"00012.50", b"1e22", b"9007199254740991"):
+        y = C.c_double()
+        assert tn.tn_fast_atof(tok, len(tok), C.byref(y)) == 0 and y.value == float(tok), tok
 
 
 def test_int_literals(tn):
