@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -51,11 +52,13 @@ struct Error : std::runtime_error {
 };
 
 namespace detail {
-// one library context per process, created on first use (the reference is single-goroutine)
+// one library context per process, created on first use (the reference is single-goroutine); on a multi-GPU node the
+// files of a conversion shard over one process per GPU: device = $MNW_DEVICE (default 0), or restrict HIP_VISIBLE_DEVICES
 inline mnw_ctx* ctx() {
     static mnw_ctx* c = nullptr;
     if (!c) {
-        int rc = mnw_ctx_create(0, &c);
+        const char* dev = std::getenv("MNW_DEVICE");
+        int rc = mnw_ctx_create(dev ? std::atoi(dev) : 0, &c);
         if (rc != MNW_OK) throw Error(std::string("minnow_hip: ") + mnw_strerror(rc), rc);
     }
     return c;
