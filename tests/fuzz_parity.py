@@ -80,8 +80,12 @@ def run(budget=60.0, seed=12345):
 
 
     t_end = time.time() + budget
+    t_print = time.time() + 60
     cases = blocks = 0
     while time.time() < t_end:
+        if time.time() > t_print:                        # a sign of life every minute (a silent GPU job looks hung)
+            print("%d batches, %d blocks so far" % (cases, blocks), flush=True)
+            t_print = time.time() + 60
         mode = ["default", "two_pass", "fused"][rng.integers(0, 3)] if rng.random() < 0.5 else "default"
         ctx = ctxs[mode]
         nj = int(rng.integers(1, 12))
