@@ -15,6 +15,8 @@ BIN = os.path.join(ROOT, "tests", "cpp", "test_minnow_host")
 
 MINH_SRC = os.path.join(ROOT, "tests", "cpp", "test_minh_host.cpp")
 MINH_BIN = os.path.join(ROOT, "tests", "cpp", "test_minh_host")
+TEXT_SRC = os.path.join(ROOT, "tests", "cpp", "test_text_host.cpp")
+TEXT_BIN = os.path.join(ROOT, "tests", "cpp", "test_text_host")
 MINP_SRC = os.path.join(ROOT, "tests", "cpp", "test_minp_host.cpp")
 MINP_BIN = os.path.join(ROOT, "tests", "cpp", "test_minp_host")
 
@@ -23,7 +25,7 @@ def _build(src=SRC, exe=BIN):
     from minnow_amd import build as b
     b.build()
     lib_dir = os.path.join(ROOT, "minnow_amd")
-    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("minnow.hpp", "minh.hpp", "minp.hpp", "minnow_hip.h")] + [b.LIB]
+    deps = [src] + [os.path.join(ROOT, "include", h) for h in ("minnow.hpp", "minh.hpp", "minp.hpp", "minnow_text.hpp", "minnow_hip.h")] + [b.LIB]
     if (not os.path.exists(exe)) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                                "-L", lib_dir, "-lminnow_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
@@ -38,6 +40,15 @@ def test_host_header_compiles_and_links():
     assert os.path.exists(MINH_BIN)
     _build(MINP_SRC, MINP_BIN)
     assert os.path.exists(MINP_BIN)
+
+
+def test_cpp_text_reader_host_only(tmp_path):
+    """include/minnow_text.hpp without a GPU: TestLineHeader, TestCommentHeader, the block chain of TestNextBlock and
+    TestRockstarHeader of go/text/text_test.go (file handling and header parsing stay on the host)"""
+    exe = _build(TEXT_SRC, TEXT_BIN)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ok: 4 text host tests" in r.stdout
 
 
 @pytest.mark.gpu
