@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- minnow column quantize + bit-pack hot path on MI355X.
 
-A step = one pass of the hot path over one synthetic float32 position column (BASELINE.json
-configs[1]: 1e8 particles, FloatGroup low=0 high=250 dx=0.001 -> pixels=250000, Gaussian positions
-wrapped into [0,250)): encode every block of the column and decode it back, inputs and
-outputs resident in HBM.  Blocks are 2^20 elements by default -- the block size of the minp files of
-configs[3] (about 1e6 particles per sub-cell, go/minp/minp.go:98-118) -- which the encode reads once
-(k_encode_reg_f32); the same column in 2^24-element blocks (two-pass encode) is reported beside it.
+A step = one pass of the hot path over one synthetic float32 position column of 1e9 particles -- the
+configuration BASELINE.json's metric is quoted on ("encode+decode GB/s (input) ... 1e9 float32 particles"); 4 GB
+of input fits one GPU many times over -- FloatGroup low=0 high=250 dx=0.001 -> pixels=250000, Gaussian positions
+wrapped into [0,250) (SURVEY.md 8d C2 at the metric's length): encode every block of the column and decode it
+back, inputs and outputs resident in HBM.  Blocks are 2^20 elements (the block size of the minp files of
+configs[3]: about 1e6 particles per sub-cell, go/minp/minp.go:98-118).  Reported beside the headline, as extra
+keys of the same JSON line: the same column in 2^24-element blocks, configs[1] (the first 1e8 particles, both
+block sizes) and one minp file cell of configs[3] (500^3 particles, 375 blocks per component).
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU); blocks shard
-embarrassingly -- every rank owns its own column, no data-path collective -- so the
-scaling is weak and `value` is the whole-job aggregate.  Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The column is cut into blocks
+and the blocks are dealt to the ranks in contiguous ranges (minnow_amd.shard.shard_range; a block's (min, bits,
+bytes) depends on that block only, go/group.go:242-255, 312-327): no data-path collective.  Weak scaling (the
+default): the global column has N x 1e9 particles, every rank owns 1e9 of them; --strong: the global column has
+1e9 particles whatever N is.  After the timed steps the ranks' (min, bits, nbytes) are gathered in block order and
+prefix-summed into the file offsets of go/block_index.go:16-35 -- a few integers per block, the only thing that
+ever crosses ranks.  `value` is the whole-job aggregate; rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -30,6 +36,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LOW, HIGH, DX = 0.0, 250.0, 0.001
+PROFILE_TAG = "r02"             # profiles/<tag>/pmc_traffic.json holds the PMC traffic of this workload
 
 
 def parse():
@@ -37,12 +44,14 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--particles", type=int, default=10**8)
+    p.add_argument("--particles", type=int, default=10**9, help="elements per rank (weak scaling) or in all (--strong)")
     p.add_argument("--block", type=int, default=2**20, help="elements per block (unit of GPU dispatch)")
     p.add_argument("--alt-block", type=int, default=2**24, help="second block size reported beside the headline (0: none)")
+    p.add_argument("--small-particles", type=int, default=10**8, help="configs[1] leg: column length (0: none)")
+    p.add_argument("--strong", action="store_true", help="N ranks share ONE column of --particles elements")
+    p.add_argument("--legs", choices=("all", "headline"), default="all", help="headline: only the metric's configuration")
+    p.add_argument("--no-minp", action="store_true", help="skip the configs[3] file-cell leg")
     p.add_argument("--two-pass", action="store_true", help="disable the single-read encode (diagnostic)")
-    p.add_argument("--big-particles", type=int, default=10**9,
-                   help="column length of the third leg (the metric's 1e9 particles); 0: none")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--group-bytes", type=int, default=0)
@@ -50,15 +59,40 @@ def parse():
     return p.parse_args()
 
 
-def make_column(n, device, seed):
-    """x = wrap(125 + 20*N(0,1)) into [0,250), Philox (torch CUDA generator), SURVEY 8d C2."""
+def make_column(n, device, seed, chunk=1 << 28):
+    """x = wrap(125 + 20*N(0,1)) into [0,250), Philox (torch CUDA generator); made in chunks so that
+    the temporaries stay small beside a 4 GB column."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    x = torch.randn(n, device=device, dtype=torch.float32, generator=g)
-    x.mul_(20.0).add_(125.0)
-    x = torch.remainder(x, 250.0)
-    x[x >= 250.0] = 0.0
-    return x.contiguous()
+    x = torch.empty(n, device=device, dtype=torch.float32)
+    for c0 in range(0, n, chunk):
+        v = x[c0: c0 + chunk]
+        v.normal_(0.0, 1.0, generator=g)
+        v.mul_(20.0).add_(125.0)
+        torch.remainder(v, 250.0, out=v)
+        v[v >= 250.0] = 0.0
+    return x
+
+
+def host_cores():
+    """(logical CPUs, physical cores) of this host, from /proc/cpuinfo"""
+    logical = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pid = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":")[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    return logical, (len(phys) or None)
 
 
 def cpu_baseline(mnw_pixels, n_threads, target_s=12.0):
@@ -97,16 +131,20 @@ def cpu_baseline(mnw_pixels, n_threads, target_s=12.0):
         t.join()
     dt = time.perf_counter() - t0
     total_bytes = 4.0 * blk * per_thread * n_threads
+    logical, phys = host_cores()
     return {
         "value": total_bytes / dt / 1e9, "unit": "GB/s", "cores": n_threads, "kind": "port",
-        "sample": "%d threads x %d blocks of 2^22 float32 (same Gaussian column shape), encode+decode with the "
-                  "literal byte-wise restatement of go/bit + group.go, %.1f s" % (n_threads, per_thread, dt),
+        "host_logical_cpus": logical, "host_physical_cores": phys,
+        "sample": "%d threads (host: %d logical CPUs, %s physical cores) x %d blocks of 2^22 float32 (same Gaussian column "
+                  "shape), encode+decode with the literal byte-wise restatement of go/bit + group.go, %.1f s"
+                  % (n_threads, logical, phys if phys else "?", per_thread, dt),
     }
 
 
-def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup, timing):
-    """Encode + decode the column in blocks of B elements: `warmup` untimed steps, exactly `steps` timed ones
-    (un-instrumented), then the same steps again with a HIP event pair around every kernel launch."""
+def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup, timing, block0=0, across_ranks=True):
+    """Encode + decode the elements [0, N) of x in blocks of B elements: `warmup` untimed steps, exactly `steps` timed
+    ones (un-instrumented), then the same steps again with a HIP event pair around every kernel launch.  block0: index
+    of the first block in the global column (the dither key of a block is its global index)."""
     nblk = (N + B - 1) // B
     # packed output: one 16-byte aligned slot per block, worst case 32 bits per element
     slot = (4 * B + 15) // 16 * 16
@@ -118,7 +156,7 @@ def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup,
     # takes (min, bits, nbytes) of every block from what THIS step's encode returned
     enc_arr = ctx.enc_batch(enc_jobs)
     dec_arr = ctx.dec_batch([mnw.DecJob(packed.data_ptr() + k * slot, y.data_ptr() + 4 * k * B, enc_jobs[k].n, 0,
-                                        0, 0, mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1, seed=1, block=k)
+                                        0, 0, mnw.FLOAT_GROUP, LOW, HIGH, pixels, 1, seed=1, block=block0 + k)
                              for k in range(nblk)])
 
     meta_buf = [None]
@@ -130,7 +168,7 @@ def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup,
         return meta
 
     def sync_all():
-        if dist is not None:
+        if dist is not None and across_ranks:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,11 +183,12 @@ def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup,
     for _ in range(steps):
         meta = step()
     torch.cuda.synchronize()
-    if dist is not None:
+    if dist is not None and across_ranks:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, device=device)
+    if across_ranks:
+        dt = shard.max_over_ranks(dt, device=device)
 
     # ---- the same K steps again with a HIP event pair around every kernel launch, recorded on the
     # stream the kernel is launched on (the context's stream).  Kept out of the region above because
@@ -177,20 +216,25 @@ def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup,
     t_enc = time_only(lambda: ctx.encode_blocks(enc_arr, stream=stream, raw=True), reps)
     t_dec = time_only(lambda: ctx.decode_blocks(dec_arr, stream=stream), reps)
 
-    # ---- sanity on the result of the last step (cheap, outside the timed region) -----------------
+    # ---- sanity on the result of the last step (cheap, outside the timed region): the reference's own criterion
+    # (|x - x'| <= dx on the ring, go/minnow_test.go:328-334) on the first and the last block.  The bit-exact
+    # comparison of this very launch with the oracle lives in tests/test_parity_gpu.py (headline tests).
     metas = ctx.metas_of(meta)
     assert all(m.status == 0 for m in metas)
-    d = (y[: 1 << 20].double() - x[: 1 << 20].double()).abs()
-    d = torch.minimum(d, 250.0 - d)
-    assert float(d.max()) <= DX * 1.01 + 1e-4, "round trip outside the reference tolerance"
+    for lo in (0, (nblk - 1) * B):
+        hi = min(lo + B, N)
+        d = (y[lo:hi].double() - x[lo:hi].double()).abs()
+        d = torch.minimum(d, 250.0 - d)
+        assert float(d.max()) <= DX * 1.01 + 1e-4, "round trip outside the reference tolerance"
     del packed
-    return {"dt": dt, "ktimes": ktimes, "metas": metas, "t_enc": t_enc, "t_dec": t_dec, "nblk": nblk, "steps": steps}
+    return {"dt": dt, "ktimes": ktimes, "metas": metas, "t_enc": t_enc, "t_dec": t_dec, "nblk": nblk, "steps": steps,
+            "N": N, "B": B}
 
 
-def rooflines(r, N, timing):
+def rooflines(r, timing):
     """algorithmic bytes / HIP-event kernel time, per launch.  float encode = (4 + b/8) B per element: one
     read of the block, one write of the stream; float decode = (b/8 + 4) B per element."""
-    ktimes, steps = r["ktimes"], r["steps"]
+    ktimes, steps, N = r["ktimes"], r["steps"], r["N"]
     if not (timing and ktimes):
         return None, None, None
     in_bytes = 4.0 * N
@@ -216,18 +260,101 @@ def rooflines(r, N, timing):
         "achieved": enc_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": enc_ach / HBM_PEAK_GBPS,
         "traffic": None,
         "algorithmic_bytes_per_elt": enc_alg / N,
+        "algorithmic_bytes_per_launch": enc_alg / launches_per_step,
         "elements_per_launch": N / launches_per_step,
         "avg_launch_us": {k: avg_us(k) for k in enc_names},
         "note": "achieved = (4 + b/8) B/elt x elements per batch / summed HIP-event time of the encode launches",
     }
     dec = {
-        "bound": "hbm", "kernel": "k_unpack_f32", "achieved": dec_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "k_unpack_f32 (float decode)", "achieved": dec_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": dec_ach / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_elt": dec_alg / N,
+        "algorithmic_bytes_per_launch": dec_alg, "elements_per_launch": float(N),
         "avg_launch_us": avg_us("k_unpack_f32"),
+        "note": "achieved = (b/8 + 4) B/elt x elements per batch / HIP-event time of the decode launch",
     }
     kernels = [{"kernel": k, "launches": v["launches"], "avg_us": 1e3 * v["total_ms"] / v["launches"]}
                for k, v in ktimes.items() if v["launches"]]
     return enc, dec, kernels
+
+
+def leg_record(r, timing, note):
+    enc, dec, _ = rooflines(r, timing)
+    N = r["N"]
+    return {
+        "particles": N, "block": r["B"], "blocks": r["nblk"], "steps": r["steps"],
+        "ms_per_step": r["dt"] / r["steps"] * 1e3, "value": 4.0 * N / (r["dt"] / r["steps"]) / 1e9, "unit": "GB/s",
+        "encode_GBps_input": 4.0 * N / r["t_enc"] / 1e9, "decode_GBps_output": 4.0 * N / r["t_dec"] / 1e9,
+        "roofline_encode": enc, "roofline_decode": dec, "note": note,
+    }
+
+
+def minp_leg(mnw, ctx, device, reps, timing):
+    """configs[3], one rank's share: one minp file cell of 500^3 particles resident on the GPU, sub_cells = 5 -> 375
+    blocks of 1e6 per component (go/minp/minp.go:98-118): mnw_vectors_encode + mnw_vectors_decode."""
+    from minnow_amd import minp
+
+    nf, S, L, dx = 500, 5, 250.0, 0.001
+    n = nf ** 3
+    g = torch.Generator(device=device)
+    g.manual_seed(0xACEDAD + 77)
+    idx = torch.arange(n, device=device)
+    pos = torch.stack([idx % nf, (idx // nf) % nf, idx // (nf * nf)], dim=1).to(torch.float32) * (L / nf)
+    del idx
+    pos.add_(torch.randn(pos.shape, device=device, generator=g).mul_(2.0))
+    pos = torch.remainder(pos, L).contiguous()
+    pos[pos >= L] = 0.0
+    n_sub = nf // S
+    nb = 3 * S ** 3
+    slot = (4 * n_sub ** 3 + 15) // 16 * 16
+    packed = torch.zeros(nb * slot, dtype=torch.uint8, device=device)
+    out = torch.empty_like(pos)
+    torch.cuda.synchronize()
+    state = {}
+
+    def enc():
+        state["m"] = minp.vectors_encode(ctx, pos.data_ptr(), nf, S, dx, True, L, packed.data_ptr(), slot)
+
+    def dec():
+        metas, low, high, pixels = state["m"]
+        minp.vectors_decode(ctx, packed.data_ptr(), slot, metas, nf, S, low, high, pixels, True, L, out.data_ptr(), seed=1)
+
+    def both():
+        enc()
+        dec()
+
+    for _ in range(4):
+        both()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        both()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / reps
+    kt = {}
+    if timing:
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(reps):
+            both()
+        torch.cuda.synchronize()
+        kt = {k: 1e3 * v["total_ms"] / v["launches"] for k, v in ctx.timing_get().items() if v["launches"]}
+        ctx.timing_enable(False)
+    metas = state["m"][0]
+    pb = float(sum(m.nbytes for m in metas))
+    d = (out.double() - pos.double()).abs()
+    d = torch.minimum(d, L - d)
+    assert float(d.max()) <= dx * 1.01 + 1e-4
+    alg = 12.0 * n + pb
+    enc_us = sum(v for k, v in kt.items() if k in ("k_reduce_vec3", "k_pack_vec3", "k_encode_vec3", "k_subcell_gather", "k_encode_reg_f32", "k_reduce_f32", "k_pack_f32"))
+    dec_us = sum(v for k, v in kt.items() if k in ("k_unpack_vec3", "k_unpack_f32", "k_subcell_scatter"))
+    rec = {"n_file": nf, "sub_cells": S, "particles": n, "blocks": nb, "bits": sorted(set(m.bits for m in metas)),
+           "ms_per_step": dt * 1e3, "value": 12.0 * n / dt / 1e9, "unit": "GB/s of input (12 B per particle), encode + decode",
+           "kernel_us": kt, "algorithmic_bytes_per_pass": alg}
+    if enc_us and dec_us:
+        rec["encode_frac_of_8TBps"] = alg / (enc_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        rec["decode_frac_of_8TBps"] = alg / (dec_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    del pos, out, packed
+    return rec
 
 
 def main():
@@ -257,7 +384,12 @@ def main():
         raise RuntimeError("bench.py needs a GPU: libminnow_hip has no CPU fallback")
 
     pixels = mnw.float_group_pixels(LOW, HIGH, DX)
-    N, B = a.particles, a.block
+    B = a.block
+    # ---- the global column and this rank's contiguous range of its blocks ---------------------
+    n_global = a.particles if a.strong else a.particles * world
+    nblk_global = (n_global + B - 1) // B
+    b_lo, b_hi = shard.shard_range(nblk_global, rank, world)
+    N = min(b_hi * B, n_global) - b_lo * B          # this rank's elements
     x = make_column(N, device, 0xACEDAD + rank)
     y = torch.empty_like(x)
     ctx = mnw.Context(local_rank)
@@ -269,21 +401,53 @@ def main():
         ctx.set_option("single_read", 0)
     timing = not a.no_kernel_timing
 
-    r = run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, a.steps, a.warmup, timing)
-    # the same column in blocks too large to be held on chip (two-pass encode): reported beside the headline
-    r_big = None
-    if a.alt_block and a.alt_block != B and world == 1:
-        r_big = run_config(mnw, shard, ctx, x, y, device, dist, N, a.alt_block, pixels, min(a.steps, 10), 2, timing)
+    r = run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, a.steps, a.warmup, timing, block0=b_lo)
 
-    # the same column shape at the length BASELINE.json's metric and target are quoted on (10^9 elements)
-    r_1e9 = None
-    if a.big_particles and a.big_particles > N and world == 1:
-        del x, y
-        torch.cuda.empty_cache()
-        xb = make_column(a.big_particles, device, 0xACEDAD + rank)
-        yb = torch.empty_like(xb)
-        r_1e9 = run_config(mnw, shard, ctx, xb, yb, device, dist, a.big_particles, B, pixels, 5, 2, timing)
-        del xb, yb
+    # ---- what a writer does with the ranks' results: (min, bits, nbytes) of every block gathered in block order,
+    # the block offsets are their prefix sum (go/block_index.go:16-35).  Metadata only; once, after the steps.
+    t0 = time.perf_counter()
+    sizes = [m.nbytes for m in r["metas"]]
+    if dist is not None:
+        counts = [shard.shard_range(nblk_global, q, world) for q in range(world)]
+        width = max(hi - lo for lo, hi in counts)
+        mine = torch.zeros((width, 3), dtype=torch.int64, device=device)
+        mine[: len(sizes)] = torch.tensor([[m.min, m.bits, m.nbytes] for m in r["metas"]], dtype=torch.int64)
+        bucket = torch.empty((world, width, 3), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(bucket, mine)
+        bucket = bucket.cpu().numpy()
+        all_sizes = [int(v) for q, (lo, hi) in enumerate(counts) for v in bucket[q, : hi - lo, 2]]
+    else:
+        all_sizes = sizes
+    offsets = shard.block_offsets(all_sizes)
+    gather_ms = (time.perf_counter() - t0) * 1e3
+    assert len(offsets) == nblk_global and offsets[-1] + all_sizes[-1] == sum(all_sizes)
+
+    # ---- extra legs (every rank runs them on its own device, rank 0 reports its own numbers) -------------------
+    extra = {}
+    if a.legs == "all":
+        if a.alt_block and a.alt_block != B:
+            rb = run_config(mnw, shard, ctx, x, y, device, dist, N, a.alt_block, pixels, min(a.steps, 5), 2, timing,
+                            across_ranks=False)
+            extra["blocks_2p%d" % (a.alt_block.bit_length() - 1)] = leg_record(
+                rb, timing, "the same column in blocks of %d elements" % a.alt_block)
+        if a.small_particles and a.small_particles < N:
+            ns = a.small_particles
+            rs = run_config(mnw, shard, ctx, x, y, device, dist, ns, B, pixels, min(a.steps, 20), 3, timing, across_ranks=False)
+            extra["column_1e8"] = leg_record(rs, timing, "BASELINE configs[1]: the first %d particles of the column, blocks of %d "
+                                             "(at this length the encode's 225 MB of streams are still in the 256 MB Infinity Cache "
+                                             "when the decode reads them)" % (ns, B))
+            if a.alt_block and a.alt_block != B:
+                rs2 = run_config(mnw, shard, ctx, x, y, device, dist, ns, a.alt_block, pixels, min(a.steps, 10), 2, timing,
+                                 across_ranks=False)
+                extra["column_1e8_blocks_2p%d" % (a.alt_block.bit_length() - 1)] = leg_record(
+                    rs2, timing, "configs[1] in blocks of %d elements (SURVEY.md 8d C2's default block)" % a.alt_block)
+        if not a.no_minp:
+            del y
+            torch.cuda.empty_cache()
+            extra["minp_cell"] = minp_leg(mnw, ctx, device, 5, timing)
+    counters = ctx.counters()
+    # the single-read kernel must never have given up (a co-tenant kernel would make it: 50 ms + a 2x slower path)
+    assert counters["single_read_aborts"] == 0, counters
 
     if rank != 0:
         if dist is not None:
@@ -292,59 +456,45 @@ def main():
 
     metas, dt = r["metas"], r["dt"]
     bits = sorted(set(m.bits for m in metas))
-    in_bytes = 4.0 * N
-    packed_bytes = float(sum(m.nbytes for m in metas))
     ms_per_step = dt / a.steps * 1e3
-    value = world * in_bytes / (dt / a.steps) / 1e9
+    value = 4.0 * n_global / (dt / a.steps) / 1e9
+    packed_bytes = float(sum(m.nbytes for m in metas))
     out = {
         "metric": "encode+decode GB/s (input)", "value": value, "unit": "GB/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
         "dtype": "f32->u32 fixed point (f32 sub/div, integer pack)", "data": "synthetic",
-        "config": {"workload": "configs[1]: single float32 position column, %d particles, FloatGroup "
-                               "low=0 high=250 dx=0.001 (pixels=%d), blocks of %d (the block size of the minp "
-                               "files of configs[3]: ~1e6 particles per sub-cell), encode+decode round trip"
-                               % (N, pixels, B),
-                   "blocks_per_gpu": r["nblk"], "bits": bits, "parallelism": "blocks sharded per GPU, no collective"},
-        "pct_hbm_peak": 100.0 * (in_bytes * 2 + 2 * packed_bytes) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
-        "encode_GBps_input": in_bytes / r["t_enc"] / 1e9, "decode_GBps_output": in_bytes / r["t_dec"] / 1e9,
+        "config": {"workload": "the metric's configuration: single float32 position column, %d particles%s, FloatGroup "
+                               "low=0 high=250 dx=0.001 (pixels=%d), blocks of %d (the block size of the minp files of "
+                               "configs[3]: ~1e6 particles per sub-cell), encode+decode round trip, device resident"
+                               % (n_global, "" if world == 1 else " in all (%d per GPU)" % N, pixels, B),
+                   "particles_per_gpu": N, "blocks_per_gpu": r["nblk"], "blocks": nblk_global, "bits": bits,
+                   "parallelism": "contiguous block ranges per GPU (shard_range), no data-path collective"},
+        "pct_hbm_peak": 100.0 * (4.0 * N * 2 + 2 * packed_bytes) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS,
+        "encode_GBps_input": 4.0 * N / r["t_enc"] / 1e9, "decode_GBps_output": 4.0 * N / r["t_dec"] / 1e9,
         "compressed_bits_per_elt": 8.0 * packed_bytes / N,
+        "block_index": {"blocks": nblk_global, "stream_bytes": int(sum(all_sizes)), "gather_and_prefix_ms": gather_ms},
+        "counters": counters,
     }
 
-    enc, dec, kernels = rooflines(r, N, timing)
+    enc, dec, kernels = rooflines(r, timing)
     if enc:
-        out["roofline"], out["roofline_decode"], out["kernels"] = enc, dec, kernels
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            # HBM bytes per launch from rocprofv3 --pmc passes (collected separately; see profiles/README.md)
+        pmc = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_traffic.json")
+        if os.path.exists(pmc) and world == 1 and N == 10**9 and B == 2**20:
+            # HBM bytes per launch from rocprofv3 --pmc passes of this very workload (collected separately; profiles/README.md)
             try:
                 with open(pmc) as f:
                     t = json.load(f)
-                out["roofline"]["traffic"] = t.get("encode_bytes_per_batch")
-                out["roofline_decode"]["traffic"] = t.get("decode_bytes_per_batch")
-                out["roofline"]["traffic_source"] = t.get("source")
+                enc["traffic"] = t.get("encode_bytes_per_launch")
+                dec["traffic"] = t.get("decode_bytes_per_launch")
+                enc["traffic_source"] = dec["traffic_source"] = t.get("source")
             except Exception:
                 pass
-    if r_big:
-        enc_b, dec_b, _ = rooflines(r_big, N, timing)
-        out["large_blocks"] = {
-            "block": a.alt_block, "steps": r_big["steps"], "ms_per_step": r_big["dt"] / r_big["steps"] * 1e3,
-            "value": in_bytes / (r_big["dt"] / r_big["steps"]) / 1e9, "unit": "GB/s",
-            "roofline": enc_b, "roofline_decode": dec_b,
-            "note": "same column, blocks of %d elements: more than the chip can hold, so the encode reads each "
-                    "block twice (reduce + pack launches)" % a.alt_block,
-        }
-
-    if r_1e9:
-        nb = a.big_particles
-        enc_b, dec_b, _ = rooflines(r_1e9, nb, timing)
-        out["column_1e9"] = {
-            "particles": nb, "block": B, "steps": r_1e9["steps"], "ms_per_step": r_1e9["dt"] / r_1e9["steps"] * 1e3,
-            "value": 4.0 * nb / (r_1e9["dt"] / r_1e9["steps"]) / 1e9, "unit": "GB/s",
-            "roofline": enc_b, "roofline_decode": dec_b,
-            "note": "same column shape and block size at %d particles (the length the metric and the 60%% target are "
-                    "quoted on): launch ramp-up and tail amortise over ten times the work" % nb,
-        }
+        # `roofline` = the dominant kernel of the step (the longer of the two launches); both are reported
+        enc_us = sum(enc["avg_launch_us"].values())
+        out["roofline"] = dict(dec if dec["avg_launch_us"] > enc_us else enc)
+        out["roofline_encode"], out["roofline_decode"], out["kernels"] = enc, dec, kernels
+    out.update(extra)
 
     if world == 1 and not a.no_cpu_baseline:
         ncpu = os.cpu_count() or 1

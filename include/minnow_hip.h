@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNW_ABI_VERSION 2   /* 2: xform field in mnw_enc_job / mnw_dec_job */
+#define MNW_ABI_VERSION 3   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MNW_OK            0
@@ -313,11 +313,27 @@ int mnw_timing_reset(mnw_ctx *ctx);
 int mnw_timing_get(mnw_ctx *ctx, mnw_kernel_time *out /* [MNW_K_COUNT] */);
 const char *mnw_kernel_name(int kernel_id);
 
+/* Event counters of the context since it was created (or since mnw_counters_reset): which encode structure the
+ * float batches took, and how often the single-read kernel gave up.  That kernel needs its whole grid co-resident
+ * (mnw_set_option: single_read); when something else holds part of the GPU its bounded wait (50 ms) expires, the
+ * host reruns the batch through the reduce + pack launches -- correct, but 50 ms and a 2x slower path, so a caller
+ * that cares about throughput watches MNW_C_SINGLE_READ_ABORTS (bench.py asserts it is 0). */
+#define MNW_C_SINGLE_READ_BATCHES 0  /* float batches encoded by k_encode_reg_f32 */
+#define MNW_C_SINGLE_READ_ABORTS  1  /* ... of which gave up and were rerun through reduce + pack (also counts fused launches) */
+#define MNW_C_TWO_PASS_BATCHES    2  /* float batches that went to the reduce + pack launches directly (not eligible / option) */
+#define MNW_C_EXACT_BLOCKS        3  /* float blocks sent to the exact sequential path (out-of-domain data) */
+#define MNW_C_FUSED_BATCHES       4  /* float batches encoded by the opt-in fused launch k_encode_f32 */
+#define MNW_C_COUNT               8
+int mnw_counters_get(mnw_ctx *ctx, int64_t out[MNW_C_COUNT]);
+int mnw_counters_reset(mnw_ctx *ctx);
+
 /* Tunables (0 = default).  group_bytes: blocks are processed in groups whose input is at most this
  * many bytes so that the pack pass re-reads its group from the Infinity Cache, not HBM.
  * fused: 1 = float batches run as one persistent launch (k_encode_f32); 0 (default) = see single_read.
- * single_read: 1 (default) = a float batch whose blocks all have at most 2^22 elements is encoded by
+ * single_read: 1 (default) = a float batch whose blocks can all be held on chip -- at most 2^24 elements each on a
+ *        whole MI355X (twice as many 8,192-element items as the launch has workgroups) -- is encoded by
  *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
+ * big_blocks: 1 (default) = that includes blocks of more than 2^22 elements; 0 = those take reduce + pack.
  * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
  *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.
  * reg_test_drop_item: test hook (default -1): the single-read kernel never publishes the statistics of that item, so

@@ -11,6 +11,8 @@ STATUS_NAMES = {
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
 K_COUNT = 19
+C_COUNT = 8
+COUNTER_NAMES = ("single_read_batches", "single_read_aborts", "two_pass_batches", "exact_blocks", "fused_batches")
 
 
 class MnwError(RuntimeError):
@@ -104,6 +106,8 @@ SIGNATURES = {
     "mnw_text_stats": (_int, [_p, C.POINTER(_i64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
+    "mnw_counters_get": (_int, [_p, C.POINTER(_i64)]),
+    "mnw_counters_reset": (_int, [_p]),
     "mnw_set_option": (_int, [_p, C.c_char_p, _i64]),
 }
 

@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so then travels to
 the GPU box with the repo snapshot.
 """
+import hashlib
 import os
 import subprocess
 
@@ -21,12 +22,25 @@ FLAGS = [
 ]
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Digest of everything the library is compiled from (sources, headers, flags): a library is reused only
+    if it was built from exactly this text, whatever the files' time stamps say."""
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False):
@@ -37,6 +51,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

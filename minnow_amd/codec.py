@@ -272,6 +272,16 @@ class Context:
     def unpack_u64_dev(self, in_ptr, in_len, bits, n, out_ptr, stream=None):
         self._check(self._L.mnw_unpack_u64_dev(self._h, stream, in_ptr, in_len, bits, n, out_ptr))
 
+    # -- counters -----------------------------------------------------------------------------
+    def counters(self):
+        """which encode structure the float batches took and how often the single-read kernel gave up (mnw_counters_get)"""
+        out = (C.c_int64 * _lib.C_COUNT)()
+        self._check(self._L.mnw_counters_get(self._h, out))
+        return {name: int(out[k]) for k, name in enumerate(_lib.COUNTER_NAMES)}
+
+    def counters_reset(self):
+        self._check(self._L.mnw_counters_reset(self._h))
+
     # -- timing ------------------------------------------------------------------------------
     def timing_enable(self, on=True):
         self._check(self._L.mnw_timing_enable(self._h, int(on)))

@@ -23,9 +23,11 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int, int);
 size_t item_rec_bytes();
 int reg_max_items_per_block();
+int reg_max_items_per_big_block();
+int reg_group_items();
 int encode_reg_f32_xf_blocks_per_cu();
 int64_t reg_item_elems();
 int encode_reg_f32_blocks_per_cu();
@@ -167,6 +169,7 @@ struct mnw_ctx {
     int reg_weighted = 1;        // single read: weighted item hand-out (see k_encode_reg_f32)
     int vec3_fused = 1;          // minp vectors: reduce + pack straight from the AoS grid when the geometry allows
     int single_read = 1;         // float encode through k_encode_reg_f32 (block read once) whenever the batch is eligible
+    int big_blocks = 1;          // ... including blocks of more than 512 items (two-level record sweep), up to twice the grid
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
@@ -174,7 +177,7 @@ struct mnw_ctx {
     size_t cap_recs = 0;
     uint32_t reg_gen = 0;        // generation tag of the records of the current batch (never 0)
     int fused_blocks_per_cu = 0; // co-resident workgroups of k_encode_f32 per CU (occupancy query)
-    int64_t fused_aborts = 0;    // fused launches that fell back to the two-kernel path
+    int64_t counters[MNW_C_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};   // mnw_counters_get
     int pend_nfloat = 0;         // device slots [0, pend_nfloat) of the pending batch are float jobs
     bool pend_fused = false;
 
@@ -528,16 +531,39 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
     if (per_cu < 1) return 1;
     int grid = c->cus * per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
-    const int max_items = grid < mnw::reg_max_items_per_block() ? grid : mnw::reg_max_items_per_block();
+    // Blocks of at most min(G, 512) items: flat record sweep, weighted hand-out.  Larger ones, up to min(2 G, 4096)
+    // items (2^24 elements on a full grid of G = 1,024): two-level sweep; beyond G items the rounds must be unweighted
+    // (see "large blocks" in mnw_kernels.hip).  `big_blocks` = 0 keeps everything above 512 items on the two-pass path.
     const int64_t item = mnw::reg_item_elems();
-    int64_t items = 0;
+    int64_t items = 0, groups = 0, max_ni = 0;
     for (int k = 0; k < nfloat; ++k) {
         const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
-        if (ni > max_items) return 1;
-        sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
+        if (ni > max_ni) max_ni = ni;
         items += ni;
     }
-    const size_t need = (size_t)items * mnw::item_rec_bytes();
+    if (items < grid) grid = items > 0 ? (int)items : 1;
+    {
+        const int64_t flat = mnw::reg_max_items_per_block();
+        int64_t lim = grid < flat ? grid : flat;
+        if (c->big_blocks) {
+            lim = 2 * (int64_t)grid;
+            if (lim > mnw::reg_max_items_per_big_block()) lim = mnw::reg_max_items_per_big_block();
+        }
+        if (max_ni > lim) return 1;
+    }
+    const bool unweighted = max_ni > grid;
+    items = 0;
+    for (int k = 0; k < nfloat; ++k) {
+        const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
+        sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
+        sl->h_jobs[k].grp0 = groups;          // ... and its group records: R x R of them (R copies of R records), large blocks only
+        items += ni;
+        if (ni > mnw::reg_max_items_per_block()) {
+            const int64_t R = (ni + mnw::reg_group_items() - 1) / mnw::reg_group_items();
+            groups += R * R;
+        }
+    }
+    const size_t need = (size_t)(items + groups) * mnw::item_rec_bytes();
     if (need > c->cap_recs) {
         // (re)allocation happens between batches only: the previous batch has been finished by then
         if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
@@ -578,11 +604,13 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         if (ints) sl->shadow_tag = 0; else remember_tables(sl, 2, table_bytes);
     }
     if (items > 0) {
-        if (items < grid) grid = (int)items;
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
-        // the weighted hand-out only when the grid is the full co-resident one (four workgroups on every CU)
-        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
-                                   sl->d_meta, grid == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item, any_xform);
+        // the weighted hand-out only when the grid is the full co-resident one (four workgroups on every CU) and no
+        // block has more items than the grid has workgroups; group records live behind the item records
+        mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs,
+                                   (uint8_t*)c->d_recs + (size_t)items * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl), sl->d_hsync,
+                                   sl->d_meta, (grid == c->cus * 4 && !unweighted) ? c->reg_weighted : 0, c->reg_drop_item, any_xform,
+                                   max_ni > mnw::reg_max_items_per_block() ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     return MNW_OK;
@@ -760,6 +788,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (1ll << 40); return MNW_OK; }
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
+    if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_weighted")) { c->reg_weighted = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_test_drop_item")) { c->reg_drop_item = value; return MNW_OK; }
@@ -812,6 +841,17 @@ int mnw_timing_get(mnw_ctx* c, mnw_kernel_time* out) {
     if (!c || !out) return MNW_E_ARG;
     collect_timing(c);
     memcpy(out, c->acc, sizeof c->acc);
+    return MNW_OK;
+}
+
+int mnw_counters_get(mnw_ctx* c, int64_t out[MNW_C_COUNT]) {
+    if (!c || !out) return MNW_E_ARG;
+    memcpy(out, c->counters, sizeof c->counters);
+    return MNW_OK;
+}
+int mnw_counters_reset(mnw_ctx* c) {
+    if (!c) return MNW_E_ARG;
+    memset(c->counters, 0, sizeof c->counters);
     return MNW_OK;
 }
 
@@ -883,7 +923,7 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
             for (int k = 0; k < nfloat; ++k) keep[k] = sl->h_jobs[k].tile0;
             rc = launch_encode_reg(c, sl, s, nfloat, nslot);
             if (rc == 1) for (int k = 0; k < nfloat; ++k) sl->h_jobs[k].tile0 = keep[k];
-            else if (rc == MNW_OK) c->pend_mode = 2;
+            else if (rc == MNW_OK) { c->pend_mode = 2; c->counters[MNW_C_SINGLE_READ_BATCHES]++; }
             else return rc;
         }
         if (rc != MNW_OK) {
@@ -894,8 +934,10 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
         if (rc == MNW_OK) {
             // launched above
         } else if (fused) {
+            c->counters[MNW_C_FUSED_BATCHES]++;
             rc = launch_encode_fused(c, sl, s, nfloat, nslot);        // its k_prepare covers all nslot jobs
         } else {
+            if (nfloat > 0) c->counters[MNW_C_TWO_PASS_BATCHES]++;
             rc = prepare_slot(c, sl, s, nslot, true);
             if (rc) return rc;
             rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
@@ -924,7 +966,7 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     if (c->pend_mode != 0 && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
         // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
         // part of the GPU): rerun the float jobs through the two-kernel path.  Still the GPU path.
-        c->fused_aborts++;
+        c->counters[MNW_C_SINGLE_READ_ABORTS]++;
         sl->shadow_tag = 0;                       // the abort word on the device is set: the next batch must prepare
         for (int k = 0, g0 = 0; g0 < c->pend_nfloat; ) {   // group-relative tile numbering again
             (void)k;
@@ -951,6 +993,7 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     for (int i = 0; i < njobs; ++i) {
         if (res[i].status == mnw::kNeedsExact) {
             Meta m;
+            c->counters[MNW_C_EXACT_BLOCKS]++;
             int rc = encode_exact_float(c, s, c->pend_jobs[i], &m);
             if (rc) return rc;
             res[i] = m;
@@ -974,6 +1017,15 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     if (c->pending) return fail(c, MNW_E_ARG, "decode: an encode batch is pending");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    // every job is checked before a ring slot is taken: a rejected batch leaves the context as it was
+    for (int i = 0; i < njobs; ++i) {
+        const mnw_dec_job& j = jobs[i];
+        if (j.n < 0 || j.bits < 0 || j.bits > 64) return fail(c, MNW_E_ARG, "decode: bits outside 0..64 or negative n");
+        if (j.kind != MNW_INT_GROUP && j.kind != MNW_FLOAT_GROUP) return fail(c, MNW_E_ARG, "decode: unknown kind");
+        if (j.n == 0) continue;
+        if (!j.dst || (j.bits > 0 && !j.src)) return fail(c, MNW_E_ARG, "decode: null pointer");
+        if (j.src_len < mnw::array_bytes(j.bits, j.n) && j.bits > 0) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
+    }
     JobSlot* sl;
     int rc = acquire_slot(c, njobs > 0 ? njobs : 1, &sl, true);
     if (rc) return rc;
@@ -985,11 +1037,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
         int64_t tiles = 0;
         for (int i = 0; i < njobs; ++i) {
             const mnw_dec_job& j = jobs[i];
-            if (j.n < 0 || j.bits < 0 || j.bits > 64) return fail(c, MNW_E_ARG, "decode: bits outside 0..64 or negative n");
-            if (j.kind != MNW_INT_GROUP && j.kind != MNW_FLOAT_GROUP) return fail(c, MNW_E_ARG, "decode: unknown kind");
             if (j.n == 0) continue;
-            if (!j.dst || (j.bits > 0 && !j.src)) return fail(c, MNW_E_ARG, "decode: null pointer");
-            if (j.src_len < mnw::array_bytes(j.bits, j.n) && j.bits > 0) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
             int jc;
             if (j.kind == MNW_INT_GROUP) jc = 2;
             else {
@@ -1685,7 +1733,7 @@ static int encode_host(mnw_ctx* c, int kind, const void* x, int64_t n, float low
     memset(&j, 0, sizeof j);
     j.src = c->d_in; j.dst = c->d_out; j.n = n; j.cap = dcap; j.pixels = pixels; j.low = low; j.high = high;
     j.kind = kind; j.periodic = periodic;
-    mnw_block_meta m;
+    mnw_block_meta m = {0, 0, 0, 0};          // (a call that fails before the metadata exists leaves zeros, not stack bytes)
     rc = mnw_encode_blocks(c, c->stream, &j, 1, &m);
     *min = m.min; *bits = m.bits;
     if (rc) return rc;

@@ -40,6 +40,7 @@ struct DevJob {
     int32_t xform;       // kXfLog10 | kXfClamp: minh's processFloatGroup on every value before it is looked at (encode);
                          // kXfLog10: 10^x on every value after the dequantize (decode)
     float high_below;    // Nextafter32(high, -Inf): what the clamp maps x >= high to
+    int64_t grp0;        // single-read encode: first group record (64 items each) of this job in the launch
 };
 
 constexpr int kModeStats = 0;

@@ -948,7 +948,12 @@ constexpr int kThreadsR = 256;
 constexpr int kItem = kThreadsR * kGroup;           // 8,192 elements: one lane packs one group of the item
 constexpr int kBufR = kThreadsR * kStride32;        // dwords of one parked item (padded stage layout)
 static_assert(kBufR * 4 == 36864, "36 KB of LDS for the parked item: four workgroups per CU");
-constexpr int kMaxSweep = 512;                      // items per block the sweep handles (2^22 elements)
+constexpr int kMaxSweep = 512;                      // items per block the flat sweep handles (2^22 elements)
+// Blocks of more items (up to kMaxBig, and up to twice the grid: see "large blocks" below) exchange their statistics in
+// two levels: the records of kGroupItems consecutive items of a block are folded into one GROUP record, and a block's
+// descriptor comes from its group records -- 64 + 64 records per workgroup and trip instead of 2,048.
+constexpr int kGroupItems = 64;                     // one record per lane of wave 0
+constexpr int kMaxBig = kGroupItems * 64;           // 4,096 items = 2^25 elements: at most 64 group records per block
 __device__ __forceinline__ int64_t items_of(int64_t n) { return (n + kItem - 1) / kItem; }
 
 struct ItemRec {                                     // 32 bytes: four {value: low 32, tag: high 32} words
@@ -1045,6 +1050,153 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
     }
 }
 
+// ---- large blocks (more than kMaxSweep items; at most min(kMaxBig, 2 G) for a grid of G workgroups, rounds unweighted) ----
+// A block of more than G items has two items in some workgroups, and such a workgroup can only pack the older one once
+// the block is complete, i.e. once EVERY workgroup has published both of its items: the chip then holds the whole block
+// (2 G items x 32 KB = 64 MB for G = 1,024: registers + LDS of all 256 CUs) and the launch advances block by block.
+// Deadlock freedom, rounds unweighted, blocks of at most 2 G items: let everything be stuck and X be the stuck workgroup
+// whose parked item p is lowest.  X's items are G apart and it has published p and c = p + G.  Every other stuck
+// workgroup Z has a parked item >= p, so it has published its first item q* >= p and q* + G; Z's items inside p's block
+// (which lies within [p - 2G + 1, p + 2G - 1]) are at most q* + G: all published (workgroups in their first trip never
+// wait; finished ones have published everything).  So every item record of p's block is out, every group of it is swept
+// by an owner Y of one of its items i -- in the trip where i is Y's parked item, or already in the trip where i is Y's
+// current item and Y's parked item belongs to the same block -- and Y cannot be stuck before that trip (its parked item
+// would be below p) nor in it before the group record is out (the sweep only needs item records).  Hence all group
+// records of p's block appear and X's wait ends: contradiction.
+//
+// wave 0 only.  Makes sure the group records of group `grp` of job jb exist: polls the item records of the group until
+// all are there, folds them and publishes the group record (every workgroup that needs the group does this; they all
+// store the same four words).  Returns false on abort.
+__device__ __forceinline__ bool poll_abort(uint32_t& spins, uint64_t t_start, uint32_t* __restrict__ abort_flag,
+                                           uint32_t* __restrict__ abort_host) {
+    __builtin_amdgcn_s_sleep(2);
+    ++spins;
+    if ((spins & 15) != 0) return false;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+    if (__builtin_amdgcn_s_memrealtime() - t_start > 5000000ull) {      // 50 ms (100 MHz counter)
+        if (lane_id() == 0) {
+            __hip_atomic_fetch_add(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word
+        }
+        return true;
+    }
+    return false;
+}
+
+#ifdef MNW_STAMPS
+__device__ unsigned long long g_big_diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls, group polls, block polls, cycles: all / group phase / block phase
+#define MNW_BIG_DIAG(i, v) if (lane_id() == 0) atomicAdd(&g_big_diag[i], (unsigned long long)(v))
+#else
+#define MNW_BIG_DIAG(i, v)
+#endif
+// One published record by two 16-byte agent-scope loads (each 8-byte word validates itself, so the halves need no
+// ordering); returns when the data is there.  Half the requests of four 8-byte loads: what a poll costs is the number of
+// requests that land on one line (they are served one after the other, about 2.5 ns each with a thousand pollers).
+__device__ __forceinline__ void load_rec_sc1(const ItemRec* p, uint64_t (&w)[4]) {
+    u32x4 a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"((const MNW_GLOBAL ItemRec*)p) : "memory");
+    w[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); w[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+}
+
+// wave 0 only.  Large blocks, the two steps of the two-level sweep:
+//   group_duty_f32: poll the item records of the group of item `it` of job j until all are there, fold them and publish
+//      the group record.  Every member of a group does this (no leader; it waits for item records only), in the trip in
+//      which `it` is its parked item -- the records are a trip old then and the kernel has loaded them at the start of
+//      the trip like the flat sweep does: this function only runs if one was missing -- or, when the workgroup's parked
+//      item belongs to the same block, already in the trip in which `it` is its current item (the block cannot complete
+//      without it): those records are fresh and this is where the chip waits for its slowest workgroup.
+//   block_desc_big_f32: the descriptor word of the parked item's block from its group records (0 on abort).
+// What a poll costs is set by how many requests hit one line: a record that all 1,024 workgroups poll takes ~10 us per
+// round.  Hence the group records exist in R copies (R = groups of the block): copy d is read only by the workgroups whose
+// parked item is in group d (64 readers per line), and member m of group g writes the copies d = m, m + cnt_g, ... of
+// record g (cnt_g = items of group g: one copy each, more only in a block's short last group).
+__device__ __forceinline__ void publish_group_rec(ItemRec* __restrict__ copies, int R, int grp, int member, int cnt,
+                                                  uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, bool anybad, uint32_t gen) {
+    const int l = lane_id();
+    const uint32_t val = l == 0 ? v0 : l == 1 ? v1 : l == 2 ? v2 : v3;
+    const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (anybad ? kRecBad : 0u)) << 32);
+    for (int d = member; d < R; d += cnt)
+        if (l < 4) __hip_atomic_store(&copies[(size_t)d * R + grp].g[l], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __attribute__((noinline)) bool group_duty_f32(const DevJob* __restrict__ jobs, int j, int64_t it,
+                                                         ItemRec* __restrict__ recs, ItemRec* __restrict__ grecs, uint32_t gen,
+                                                         uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ abort_host) {
+    const int64_t tile0 = jobs[j].tile0, grp0 = jobs[j].grp0;
+    const int nitems = (int)items_of(jobs[j].n);
+    const int R = (nitems + kGroupItems - 1) / kGroupItems;
+    const int l = lane_id();
+    uint32_t spins = 0;
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+    const int grp = (int)(it - tile0) / kGroupItems;
+    const int first = grp * kGroupItems;
+    const int cnt = nitems - first < kGroupItems ? nitems - first : kGroupItems;
+    const int member = (int)(it - tile0) - first;
+    const ItemRec* r0 = recs + tile0 + first;
+    ItemRec* const copies = grecs + grp0;                    // [R reader groups][R group records]
+    MNW_BIG_DIAG(0, 1);
+    for (;;) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        uint32_t bad = 0, missing = 0;
+        if (l < cnt) {
+            load_rec_sc1(r0 + l, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t tag = (uint32_t)(w[k] >> 32);
+                missing |= (tag & ~kRecBad) != gen;
+                bad |= tag & kRecBad;
+            }
+        }
+        if (!__any(missing)) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(l < cnt ? (uint32_t)w[k] : 0u);
+            publish_group_rec(copies, R, grp, member, cnt, v[0], v[1], v[2], v[3], __any(bad), gen);
+            return true;
+        }
+        MNW_BIG_DIAG(1, 1);
+        if (poll_abort(spins, t_start, abort_flag, abort_host)) return false;
+    }
+}
+
+__device__ __attribute__((noinline)) uint64_t block_desc_big_f32(const DevJob* __restrict__ jobs, int j, int64_t pit,
+                                                                 ItemRec* __restrict__ grecs, uint32_t gen,
+                                                                 uint32_t* __restrict__ abort_flag, uint32_t* __restrict__ abort_host,
+                                                                 Meta* __restrict__ meta) {
+    const DevJob jb = jobs[j];
+    const int nitems = (int)items_of(jb.n);
+    const int R = (nitems + kGroupItems - 1) / kGroupItems;
+    const int l = lane_id();
+    uint32_t spins = 0;
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+    const int g_prev = (int)(pit - jb.tile0) / kGroupItems;
+    const ItemRec* gr = grecs + jb.grp0 + (size_t)g_prev * R;     // copy g_prev of the block's R group records
+    MNW_BIG_DIAG(3, 1);
+    for (;;) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        uint32_t bad = 0, missing = 0;
+        if (l < R) {
+            load_rec_sc1(gr + l, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t tag = (uint32_t)(w[k] >> 32);
+                missing |= (tag & ~kRecBad) != gen;
+                bad |= tag & kRecBad;
+            }
+        }
+        if (!__any(missing)) {
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(l < R ? (uint32_t)w[k] : 0u);
+            return desc_from_sweep_f32(jb, j, v[0], v[1], v[2], v[3], __any(bad), meta, pit == jb.tile0);
+        }
+        MNW_BIG_DIAG(2, 1);
+        if (poll_abort(spins, t_start, abort_flag, abort_host)) return 0;
+    }
+}
+
 // round sizes of the weighted item hand-out, in quarters of the grid (see k_encode_reg_f32)
 constexpr int kRounds = 14;
 __constant__ int kRoundQuarters[kRounds] = {4, 4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 2, 4};      // 14 / 12 / 11 / 10 items per cycle
@@ -1058,10 +1210,12 @@ __device__ unsigned long long g_slow_sweeps = 0;
 // no scalar or vector register to spare, and carrying the transform's code and state cost it 6 %.  (The XF one
 // spills ~30 registers at four workgroups per CU and is still faster that way than at three without spills:
 // 5.8 vs 6.8 ms for the 24 float columns of tools/bench_c3.py.)
-template <bool XF>
+// BIG: the batch has blocks of more than kMaxSweep items (two-level sweep: group_duty_f32, block_desc_big_f32).  Also an instantiation of its
+// own: the extra call site costs the plain kernel scratch traffic on its critical path.
+template <bool XF, bool BIG>
 __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
                                                                  int64_t total_items, const int* __restrict__ item_job,
-                                                                 ItemRec* __restrict__ recs,
+                                                                 ItemRec* __restrict__ recs, ItemRec* __restrict__ grecs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
                                                                  uint32_t* __restrict__ abort_host,
                                                                  Meta* __restrict__ meta, int weighted, int64_t test_drop_item) {
@@ -1134,6 +1288,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     bool have_cur = it < total_items;
     if (have_cur) { locate(it); issue(); }
     bool have_prev = false;
+    int desc_job = -1;          // BIG, wave 0: the job whose descriptor word is desc_word
+    uint64_t desc_word = 0;
     int pj = 0;                 // the parked item
     int64_t pbase = 0, pit = 0;
 
@@ -1162,9 +1318,15 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             pitems = (int)items_of(pjb.n);
             const ItemRec* r0 = recs + pjb.tile0;
             const uint64_t neutral = (uint64_t)gen << 32;
+            // (a large block: the records of the parked item's GROUP, lanes 0..63 -- see group_duty_f32)
+            int nload = pitems, first = 0;
+            if (BIG && pitems > kMaxSweep) {
+                first = (int)(pit - pjb.tile0) / kGroupItems * kGroupItems;
+                nload = pitems - first < kGroupItems ? pitems - first : kGroupItems;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                sw[k] = tid < pitems ? __hip_atomic_load(&r0[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
+                sw[k] = tid < nload ? __hip_atomic_load(&r0[first + tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
         }
 
         if (have_cur) {
@@ -1242,7 +1404,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                     const uint32_t val = (uint32_t)sw[k];
                     v[k] = val > v[k] ? val : v[k];
                 }
-                if (h == 1 || pitems <= kThreadsR) break;
+                if (h == 1 || pitems <= kThreadsR || (BIG && pitems > kMaxSweep)) break;
                 const ItemRec* r1 = recs + pjb.tile0 + kThreadsR;
                 const uint64_t neutral = (uint64_t)gen << 32;
 #pragma unroll
@@ -1292,7 +1454,25 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
 #ifdef MNW_DIAG_NOWAIT
                 fl &= ~1u;                           // diagnostic build: never wait for a record (output is then wrong)
 #endif
-                if (__builtin_expect(fl & 1u, 0)) {
+                if (BIG && pitems > kMaxSweep) {
+                    // a large block.  Its descriptor may be known from the trip before (the workgroup's previous item was in
+                    // the same block); else: the current item's group first if that is part of the block, then the sweep
+                    if (pj == desc_job) g = desc_word;
+                    else {
+                        // the group of the parked item: from the records loaded at the start of the trip, if they were all there
+                        bool ok2 = true;
+                        if (fl & 1u) ok2 = group_duty_f32(jobs, pj, pit, recs, grecs, gen, abort_flag, abort_host);
+                        else {
+                            const int first = (int)(pit - pjb.tile0) / kGroupItems * kGroupItems;
+                            const int cnt = pitems - first < kGroupItems ? pitems - first : kGroupItems;
+                            publish_group_rec(grecs + pjb.grp0, (pitems + kGroupItems - 1) / kGroupItems, first / kGroupItems,
+                                              (int)(pit - pjb.tile0) - first, cnt, v0, v1, v2, v3, (fl & 2u) != 0, gen);
+                        }
+                        if (ok2 && have_cur && sj == pj) ok2 = group_duty_f32(jobs, sj, sit, recs, grecs, gen, abort_flag, abort_host);
+                        g = ok2 ? block_desc_big_f32(jobs, pj, pit, grecs, gen, abort_flag, abort_host, meta) : 0;
+                        desc_job = pj; desc_word = g;
+                    }
+                } else if (__builtin_expect(fl & 1u, 0)) {
 #ifdef MNW_STAMPS
                     if (lane_id() == 0) atomicAdd(&g_slow_sweeps, 1ull);
 #endif
@@ -1396,6 +1576,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             }
             if (have_next) issue();
             MNW_STAMP(5)      // park + next loads issued
+
         }
         have_prev = have_cur;
         pj = sj; pbase = sbase; pit = sit;
@@ -1854,26 +2035,28 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 }
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t test_drop_item,
-                           int any_xform) {
-    if (any_xform)
-        hipLaunchKernelGGL(k_encode_reg_f32<true>, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
-                           abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
-    else
-        hipLaunchKernelGGL(k_encode_reg_f32<false>, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
-                           abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, test_drop_item);
+                           void* grecs, uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted,
+                           int64_t test_drop_item, int any_xform, int big) {
+    const int w = (weighted && grid % 4 == 0) ? 1 : 0;
+#define MNW_LAUNCH_REG(XF, BIG) hipLaunchKernelGGL((k_encode_reg_f32<XF, BIG>), dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, \
+                                                   (ItemRec*)recs, (ItemRec*)grecs, gen, abort_flag, abort_host, meta, w, test_drop_item)
+    if (any_xform) { if (big) MNW_LAUNCH_REG(true, true); else MNW_LAUNCH_REG(true, false); }
+    else { if (big) MNW_LAUNCH_REG(false, true); else MNW_LAUNCH_REG(false, false); }
+#undef MNW_LAUNCH_REG
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }
+int reg_max_items_per_big_block() { return kMaxBig; }
+int reg_group_items() { return kGroupItems; }
 int64_t reg_item_elems() { return kItem; }
 int encode_reg_f32_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<false>, kThreadsR, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<false, true>, kThreadsR, 0) != hipSuccess) return 0;
     return n;
 }
 int encode_reg_f32_xf_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<true>, kThreadsR, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_f32<true, true>, kThreadsR, 0) != hipSuccess) return 0;
     return n;
 }
 int encode_f32_blocks_per_cu() {

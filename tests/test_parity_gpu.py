@@ -462,8 +462,12 @@ def test_encode_structures_bit_exact(mnw, oracle, torch_mod, mode):
     rng = np.random.default_rng(21)
     low, high, pixels = 0.0, 250.0, 250000
     sizes = [1, 63, 8191, 8192, 8193, 16384, 16385, 40000, 100001, 300000, 2**20 + 17, 2**21 + 5]
-    if mode != "single_read":
-        sizes.append(5 * 2**20)                 # more items than the single-read kernel takes: two-pass anyway
+    if mode == "single_read":
+        sizes.append(2**24)                     # SURVEY 8d C2's default block: still read once (two-level record sweep)
+    else:
+        sizes.append(5 * 2**20)
+    if mode == "two_pass":
+        sizes.append(10**8)                     # a whole column as ONE block: more than the chip holds, two-pass in any mode
     xs = []
     for k, n in enumerate(sizes):
         c, sg = [(125.0, 20.0), (0.2, 0.4), (249.8, 0.5), (60.0, 0.01)][k % 4]
@@ -482,17 +486,17 @@ def test_encode_structures_bit_exact(mnw, oracle, torch_mod, mode):
             c2.set_option("single_read", 0)
         c2.set_option("group_bytes", 3 << 20)      # several groups for the fused form
         ts = [torch.from_numpy(x).to(dev) for x in xs]
-        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]   # the NaN block needs 64 bits
+        outs = [torch.zeros((8 if x.size < 10**6 else 4) * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]   # the NaN block needs 64 bits
         jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
                 for t, o in zip(ts, outs)]
         torch.cuda.synchronize()
         c2.timing_enable(True)
         c2.timing_reset()
+        wants = [oracle.float_encode(x, low, high, pixels, True, literal=False) for x in xs]
         for rep in range(3):                        # slots are reused: stale sync words would show up here
             metas = c2.encode_blocks(jobs)
             torch.cuda.synchronize()
-            for x, m, o in zip(xs, metas, outs):
-                omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
+            for (omin, obits, odata), m, o in zip(wants, metas, outs):
                 assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
                 assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
         # the structure under test is the one that ran
@@ -543,29 +547,89 @@ def test_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
         assert c2.timing_get()["k_pack_f32"]["launches"] == 0
 
 
-def test_single_read_falls_back_for_large_blocks(mnw, oracle, torch_mod):
-    """A batch with a block of more items than the single-read kernel may hold on chip takes the two-pass
-    path as a whole (same bytes either way)."""
-    torch = torch_mod
+def _encode_and_compare(mnw, oracle, torch, c2, xs, low=0.0, high=250.0, pixels=250000, reps=1):
     dev = torch.device("cuda:0")
-    rng = np.random.default_rng(22)
-    low, high, pixels = 0.0, 250.0, 250000
-    xs = [np.mod(125 + 20 * rng.standard_normal(n), 250.0).astype(np.float32) for n in (2**22 + 8192 + 3, 5000)]
-    with mnw.Context(0) as c2:
-        ts = [torch.from_numpy(x).to(dev) for x in xs]
-        outs = [torch.zeros(4 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
-        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
-                for t, o in zip(ts, outs)]
-        torch.cuda.synchronize()
-        c2.timing_enable(True)
+    ts = [torch.from_numpy(x).to(dev) for x in xs]
+    # (a block with a NaN quantizes to MinInt64 somewhere and needs 64 bits per element: go/group.go:318-320 on amd64)
+    outs = [torch.zeros((4 if np.isfinite(x).all() else 8) * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+    jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
+            for t, o in zip(ts, outs)]
+    want = [oracle.float_encode(x, low, high, pixels, True, literal=False) for x in xs]
+    torch.cuda.synchronize()
+    for _ in range(reps):
         metas = c2.encode_blocks(jobs)
         torch.cuda.synchronize()
+        for k, (m, o, (omin, obits, odata)) in enumerate(zip(metas, outs, want)):
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), k
+            assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), k
+    return metas
+
+
+def test_single_read_falls_back_for_blocks_beyond_the_chip(mnw, oracle, torch_mod):
+    """A batch with a block of more items than the chip can hold (twice the grid of the single-read kernel: 2^24
+    elements on a whole MI355X) takes the two-pass path as a whole -- same bytes either way.  With big_blocks = 0 that
+    already happens above 2^22 elements."""
+    rng = np.random.default_rng(22)
+    xs = [np.mod(125 + 20 * rng.standard_normal(n), 250.0).astype(np.float32) for n in (2**24 + 8192 + 3, 5000)]
+    with mnw.Context(0) as c2:
+        c2.timing_enable(True)
+        _encode_and_compare(mnw, oracle, torch_mod, c2, xs)
         kt = c2.timing_get()
         assert kt["k_pack_f32"]["launches"] >= 1 and not kt.get("k_encode_reg_f32", {"launches": 0})["launches"]
-        for x, m, o in zip(xs, metas, outs):
-            omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False)
-            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
-            assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        assert c2.counters()["two_pass_batches"] == 1
+    with mnw.Context(0) as c2:
+        c2.set_option("big_blocks", 0)
+        c2.timing_enable(True)
+        _encode_and_compare(mnw, oracle, torch_mod, c2, [xs[0][: 2**22 + 8192 + 3], xs[1]])
+        kt = c2.timing_get()
+        assert kt["k_pack_f32"]["launches"] >= 1 and not kt.get("k_encode_reg_f32", {"launches": 0})["launches"]
+
+
+@pytest.mark.parametrize("shape", ["2p24", "mixed", "one_and_a_half_grids", "wrapped_and_constant"])
+def test_single_read_large_blocks_bit_exact(mnw, oracle, torch_mod, shape):
+    """Blocks of more than 2^22 elements, up to twice the grid's items, are read once too (two-level record sweep,
+    k_encode_reg_f32<.., BIG>): same (min, bits) and bytes as the oracle; the launch that ran is the single-read one."""
+    rng = np.random.default_rng(26)
+
+    def col(n, c=125.0, sg=20.0):
+        x = np.mod(c + sg * rng.standard_normal(n), 250.0).astype(np.float32)
+        x[x >= np.float32(250.0)] = 0.0
+        return x
+
+    if shape == "2p24":
+        xs = [col(2**24), col(2**24, 60.0, 3.0), col(2**24 - 5)]                    # SURVEY 8d C2's default block size, three of them
+    elif shape == "mixed":
+        xs = [col(2**20), col(2**23 + 12345), col(77), col(2**22 + 8192 + 3, 249.9, 0.5), col(2**20 + 1), col(2**24), col(3 * 8192)]
+    elif shape == "one_and_a_half_grids":
+        xs = [col(1536 * 8192 + 17), col(1025 * 8192), col(513 * 8192 - 1), col(2047 * 8192 + 1)]
+    else:
+        a = col(2**23 + 999, 0.1, 0.3)                                              # ring wrapped: pmin != 0
+        b = np.full(2**23 + 4096, 25.0, dtype=np.float32)                           # constant: bits == 0
+        c = col(2**23); c[123456] = np.nan                                          # exact path behind a large block
+        xs = [a, b, c]
+    with mnw.Context(0) as c2:
+        c2.timing_enable(True)
+        _encode_and_compare(mnw, oracle, torch_mod, c2, xs, reps=2)
+        kt = c2.timing_get()
+        assert kt["k_encode_reg_f32"]["launches"] == 2, kt
+        if shape != "wrapped_and_constant":
+            assert not kt.get("k_pack_f32", {"launches": 0})["launches"]
+        cn = c2.counters()
+        assert cn["single_read_batches"] == 2 and cn["single_read_aborts"] == 0 and cn["two_pass_batches"] == 0
+
+
+def test_single_read_large_block_abort_and_fallback(mnw, oracle, torch_mod):
+    """The bounded wait of the two-level sweep: a dropped item record in a 2^24-element block makes the launch give up
+    and the host rerun the batch through reduce + pack."""
+    rng = np.random.default_rng(27)
+    xs = [np.mod(125 + 20 * rng.standard_normal(2**24), 250.0).astype(np.float32)]
+    with mnw.Context(0) as c2:
+        c2.set_option("reg_test_drop_item", 1500)
+        c2.timing_enable(True)
+        _encode_and_compare(mnw, oracle, torch_mod, c2, xs)
+        kt = c2.timing_get()
+        assert kt["k_encode_reg_f32"]["launches"] == 1 and kt["k_pack_f32"]["launches"] >= 1
+        assert c2.counters()["single_read_aborts"] == 1
 
 
 def test_repeated_batches_reuse_device_tables(mnw, oracle, torch_mod):
@@ -777,3 +841,94 @@ def test_many_small_blocks_in_one_batch(mnw, ctx, oracle, torch_mod):
         omin, obits, odata = oracle.float_encode(x, low, high, pixels, True, literal=False) if kind == "f" else oracle.int_encode(x, literal=False)
         assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
         assert host[o0: o0 + m.nbytes].tobytes() == odata.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# the headline launch itself, block by block against the oracle: bench.py's column, bench.py's block size,
+# one batch = one k_encode_reg_f32 launch (asserted), then the decode of the same batch
+# ------------------------------------------------------------------------------------------------
+def _headline_column(torch, n, seed=0xACEDAD, chunk=1 << 28):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.empty(n, device=dev, dtype=torch.float32)
+    for c0 in range(0, n, chunk):
+        v = x[c0: c0 + chunk]
+        v.normal_(0.0, 1.0, generator=g)
+        v.mul_(20.0).add_(125.0)
+        torch.remainder(v, 250.0, out=v)
+        v[v >= 250.0] = 0.0
+    return x
+
+
+def _headline_check(mnw, oracle, torch, N, B, check_blocks, expect_kernel="k_encode_reg_f32"):
+    """Encode the whole column as ONE batch, decode it as one batch, and compare the blocks in `check_blocks` -- their
+    (min, bits, nbytes), every stream byte and every decoded float -- with the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+    dev = torch.device("cuda:0")
+    low, high, pixels = 0.0, 250.0, 250000
+    x = _headline_column(torch, N)
+    y = torch.empty_like(x)
+    nblk = (N + B - 1) // B
+    slot = (4 * B + 15) // 16 * 16
+    packed = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
+    ctx = mnw.Context(0)
+    try:
+        jobs = [mnw.EncJob(x.data_ptr() + 4 * k * B, packed.data_ptr() + k * slot, min(B, N - k * B), slot,
+                           mnw.FLOAT_GROUP, low, high, pixels, 1) for k in range(nblk)]
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        metas = ctx.encode_blocks(jobs)
+        kt = ctx.timing_get()
+        ran = {k: v["launches"] for k, v in kt.items() if v["launches"]}
+        assert ran == {expect_kernel: 1} if isinstance(expect_kernel, str) else ran == expect_kernel, ran
+        assert ctx.counters()["single_read_aborts"] == 0
+        assert all(m.status == 0 for m in metas)
+        djobs = [mnw.DecJob(packed.data_ptr() + k * slot, y.data_ptr() + 4 * k * B, jobs[k].n, metas[k].nbytes, metas[k].min,
+                            metas[k].bits, mnw.FLOAT_GROUP, low, high, pixels, 1, seed=7, block=k) for k in range(nblk)]
+        ctx.decode_blocks(djobs)
+        torch.cuda.synchronize()
+        assert ctx.timing_get()["k_unpack_f32"]["launches"] == 1
+
+        def one(k):
+            n = jobs[k].n
+            xb = x[k * B: k * B + n].cpu().numpy()
+            omin, obits, odata = oracle.float_encode(xb, low, high, pixels, True, literal=False)
+            if (metas[k].min, metas[k].bits, metas[k].nbytes) != (omin, obits, odata.size):
+                return "block %d: (min, bits, nbytes) %r, oracle %r" % (k, (metas[k].min, metas[k].bits, metas[k].nbytes), (omin, obits, odata.size))
+            got = packed[k * slot: k * slot + odata.size].cpu().numpy()
+            if got.tobytes() != odata.tobytes():
+                return "block %d: stream differs from the oracle" % k
+            want = oracle.float_decode(odata, omin, obits, low, high, pixels, True, n, u=oracle.dither(7, k, n), literal=False)
+            yb = y[k * B: k * B + n].cpu().numpy()
+            if not np.array_equal(yb.view(np.uint32), want.view(np.uint32)):
+                return "block %d: decoded floats differ from the oracle" % k
+            d = np.abs(yb.astype(np.float64) - xb.astype(np.float64))
+            d = np.minimum(d, 250.0 - d)
+            if d.max() > 0.001 * 1.01 + 1e-4:
+                return "block %d: |x - x'| > dx" % k
+            return None
+
+        with ThreadPoolExecutor(max_workers=8) as ex:          # the oracle's C calls release the GIL
+            bad = [r for r in ex.map(one, check_blocks) if r]
+        assert not bad, bad[:5]
+    finally:
+        ctx.close()
+    return nblk
+
+
+def test_headline_1e8_every_block_vs_oracle(mnw, oracle, torch_mod):
+    """BASELINE configs[1] as bench.py runs it (1e8 particles, 96 blocks of 2^20): EVERY block of the single-read launch."""
+    N, B = 10**8, 2**20
+    nblk = (N + B - 1) // B
+    assert _headline_check(mnw, oracle, torch_mod, N, B, range(nblk)) == 96
+
+
+def test_headline_1e9_sampled_blocks_vs_oracle(mnw, oracle, torch_mod):
+    """The metric's configuration (1e9 particles, 954 blocks of 2^20, one launch): every 16th block, the first and the
+    (ragged) last one."""
+    N, B = 10**9, 2**20
+    nblk = (N + B - 1) // B
+    blocks = sorted(set(range(0, nblk, 16)) | {0, nblk - 1})
+    assert _headline_check(mnw, oracle, torch_mod, N, B, blocks) == 954

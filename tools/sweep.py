@@ -62,7 +62,7 @@ def run(B, grid, group_mb, fused=0, single=1):
     print("      events:", ks, flush=True)
 
 for bl in a.blocks.split(","):
-    B = N if bl == "all" else 1 << int(bl)
+    B = N if bl == "all" else int(bl[1:]) * 8192 if bl.startswith("x") else 1 << int(bl)      # "x513": blocks of 513 items of 8,192
     for gr in a.grids.split(","):
         for gp in a.groups.split(","):
             for fu in a.fused.split(","):
