@@ -475,6 +475,8 @@ def main():
         "compressed_bits_per_elt": 8.0 * packed_bytes / N,
         "block_index": {"blocks": nblk_global, "stream_bytes": int(sum(all_sizes)), "gather_and_prefix_ms": gather_ms},
         "counters": counters,
+        "device": {"name": torch.cuda.get_device_name(local_rank),
+                   "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)},
     }
 
     enc, dec, kernels = rooflines(r, timing)

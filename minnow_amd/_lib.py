@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(HERE, "libminnow_hip.so")
+_LIB = os.environ.get("MNW_LIB_PATH") or os.path.join(HERE, "libminnow_hip.so")   # (MNW_LIB_PATH: A/B runs of two builds)
 
 MNW_OK = 0
 STATUS_NAMES = {

@@ -3,6 +3,7 @@
 kernel_stats.csv (our kernels only), pmc_fetch_size.csv / pmc_write_size.csv (per-dispatch counter values of
 our kernels) and pmc_traffic.json (HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes)."""
 import collections
+import re
 import csv
 import glob
 import json
@@ -28,7 +29,7 @@ with open(os.path.join(dst, "kernel_stats.csv"), "w", newline="") as g:
     w.writeheader()
     for r in rows:
         if "mnw::" in r["Name"]:
-            r["Name"] = r["Name"].split("(")[0]
+            r["Name"] = r["Name"].split("(")[0].replace("void ", "")
             w.writerow(r)
 
 # ---- PMC passes ---------------------------------------------------------------------------------------
@@ -43,7 +44,7 @@ for sub, ctr, name in (("fetch", "FETCH_SIZE", "pmc_fetch_size.csv"), ("write", 
             if "mnw::" not in k or r["Counter_Name"] != ctr:
                 continue
             w.writerow([r["Dispatch_Id"], k, r["Grid_Size"], r["Workgroup_Size"], ctr, r["Counter_Value"]])
-            per[k.replace("void ", "").replace("mnw::", "").replace("<true>", "").replace("<false>", "")][ctr].append(float(r["Counter_Value"]))
+            per[re.sub(r"<.*", "", k.replace("void ", "").replace("mnw::", ""))][ctr].append(float(r["Counter_Value"]))
 
 kern = {}
 for k, d in per.items():
@@ -58,22 +59,20 @@ for k, d in per.items():
                "write_bytes": wk * 1024.0, "launches_sampled": len(fs)}
 
 res = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py "
-              "--steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --big-particles 0`, %s; FETCH_SIZE doubled (gfx950 reports half "
-              "the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM), WRITE_SIZE as is; both counters are in KiB" % tag,
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 "
+              "--warmup 1 --legs headline --no-cpu-baseline --no-kernel-timing` (one 1e9-element float32 column, blocks of 2^20), "
+              "%s; FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM), WRITE_SIZE "
+              "as is; both counters are in KiB" % tag,
     "kernels": kern,
 }
 enc = kern.get("k_encode_reg_f32")
 if enc:
-    res["encode_bytes_per_batch"] = enc["read_bytes_corrected"] + enc["write_bytes"]
-two = [kern[k] for k in ("k_reduce_f32", "k_pack_f32") if k in kern]
-if len(two) == 2:
-    res["encode_two_pass_bytes_per_batch"] = sum(t["read_bytes_corrected"] + t["write_bytes"] for t in two)
+    res["encode_bytes_per_launch"] = enc["read_bytes_corrected"] + enc["write_bytes"]
 dec = kern.get("k_unpack_f32")
 if dec:
-    res["decode_bytes_per_batch"] = dec["read_bytes_corrected"] + dec["write_bytes"]
-res["algorithmic_encode_bytes_per_batch"] = 625000000.0
-res["algorithmic_decode_bytes_per_batch"] = 625000000.0
+    res["decode_bytes_per_launch"] = dec["read_bytes_corrected"] + dec["write_bytes"]
+res["algorithmic_encode_bytes_per_launch"] = 6250000000.0      # (4 + 18/8) B x 1e9 elements
+res["algorithmic_decode_bytes_per_launch"] = 6250000000.0
 json.dump(res, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v["read_bytes_corrected"] / 1e6, v["write_bytes"] / 1e6) for k, v in kern.items()}, indent=1))
 for r in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
