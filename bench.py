@@ -387,9 +387,7 @@ def main():
     B = a.block
     # ---- the global column and this rank's contiguous range of its blocks ---------------------
     n_global = a.particles if a.strong else a.particles * world
-    nblk_global = (n_global + B - 1) // B
-    b_lo, b_hi = shard.shard_range(nblk_global, rank, world)
-    N = min(b_hi * B, n_global) - b_lo * B          # this rank's elements
+    nblk_global, b_lo, b_hi, N = shard.rank_plan(n_global, B, rank, world)     # N: this rank's elements
     x = make_column(N, device, 0xACEDAD + rank)
     y = torch.empty_like(x)
     ctx = mnw.Context(local_rank)
@@ -406,18 +404,8 @@ def main():
     # ---- what a writer does with the ranks' results: (min, bits, nbytes) of every block gathered in block order,
     # the block offsets are their prefix sum (go/block_index.go:16-35).  Metadata only; once, after the steps.
     t0 = time.perf_counter()
-    sizes = [m.nbytes for m in r["metas"]]
-    if dist is not None:
-        counts = [shard.shard_range(nblk_global, q, world) for q in range(world)]
-        width = max(hi - lo for lo, hi in counts)
-        mine = torch.zeros((width, 3), dtype=torch.int64, device=device)
-        mine[: len(sizes)] = torch.tensor([[m.min, m.bits, m.nbytes] for m in r["metas"]], dtype=torch.int64)
-        bucket = torch.empty((world, width, 3), dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(bucket, mine)
-        bucket = bucket.cpu().numpy()
-        all_sizes = [int(v) for q, (lo, hi) in enumerate(counts) for v in bucket[q, : hi - lo, 2]]
-    else:
-        all_sizes = sizes
+    rows = shard.gather_block_meta([(m.min, m.bits, m.nbytes) for m in r["metas"]], nblk_global, rank, world, device=device)
+    all_sizes = [row[2] for row in rows]
     offsets = shard.block_offsets(all_sizes)
     gather_ms = (time.perf_counter() - t0) * 1e3
     assert len(offsets) == nblk_global and offsets[-1] + all_sizes[-1] == sum(all_sizes)

@@ -233,8 +233,11 @@ int mnw_minh_selftest(mnw_ctx *ctx, int which, uint64_t first, uint64_t count, u
  * *n_rows = lines kept.  Every kept line must have as many fields as the first kept line has whitespace-separated
  * words (parse.go:96-103); a line that does not, or a field that Atoi / ParseFloat would reject, gives MNW_E_DOMAIN
  * (the reference panics) with the line in mnw_last_error; with no requested column nothing is checked, as in the reference
- * (parse.go:83, 132).  Literals the device does not convert itself (more than 19 digits, exponents beyond 10^+-22, inf / nan,
- * hex floats) are converted on the host with strtod from `text`.  Synchronous. */
+ * (parse.go:83, 132).  A field may be requested more than once, also as both types: every output is filled, as by the
+ * reference (text.go:202-221).  Decimal literals of up to 19 significant digits are converted on the device (exactly: Clinger's
+ * fast path, else a 128-bit power-of-ten table); what is left -- more digits, subnormal or overflowing values, inf / nan,
+ * hexadecimal floats, digit separators -- is converted on the host from `text` with ParseFloat's rules (any number of them).
+ * Synchronous. */
 int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t sep, uint8_t comment,
                    const int32_t *float_cols, int n_float, float *const *float_out,
                    const int32_t *int_cols, int n_int, int64_t *const *int_out,

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <errno.h>
 #include <ctype.h>
+#include <locale.h>
 
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ struct TextState { unsigned long long err_line; unsigned int n_slow; unsigned in
 void launch_text_count(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, int64_t*);
 void launch_text_scan(hipStream_t, int64_t*, int64_t, TextState*);
 void launch_text_parse(hipStream_t, const uint8_t*, int64_t, uint8_t, uint8_t, const int64_t*, const TextCols&, int64_t, TextSlow*, unsigned, TextState*);
+void launch_text_patch(hipStream_t, const TextSlow*, unsigned, const TextCols&);
 constexpr int kCutTile = 2048, kCutMaxCols = 64;
 struct CutCols { const void* src[kCutMaxCols]; void* dst[kCutMaxCols]; uint8_t esz[kCutMaxCols]; int32_t n; };
 void launch_cut_count(hipStream_t, const float*, float, int64_t, int64_t*);
@@ -144,6 +146,7 @@ struct mnw_ctx {
     size_t cap_text = 0, cap_tile = 0;
     void* d_text = nullptr; void* d_tile = nullptr;
     void* d_tslow = nullptr; void* d_tstate = nullptr;
+    size_t cap_tslow = 0;                           // literals the slow list holds (grows when a block needs more)
     const uint8_t* text_res = nullptr;              // host text whose copy, tile counts and prefixes are on the device (mnw_text_rows)
     int64_t text_res_n = 0, text_res_lines = 0, text_res_rows = 0;
     uint8_t text_res_sep = 0, text_res_comm = 0;
@@ -323,6 +326,19 @@ struct ScopedTimer {   // event pair around one kernel launch, on the launch's o
 int pack_grid_for(mnw_ctx* c, int64_t tiles) {
     int cap = c->grid_cap > 0 ? c->grid_cap : c->cus * 4;
     return (int)(tiles < cap ? (tiles > 0 ? tiles : 1) : cap);
+}
+
+// Decode launches are NOT persistent: about four tiles (32 KB of float output) per workgroup, tens of thousands of
+// workgroups for a long column.  Measured on a 1e9-element column (tools/ab_option.py grid_cap): 2,048 persistent workgroups
+// 1.28 ms, 16,384: 1.21, 65,536: 1.15, 131,072: 1.14, 262,144 (two tiles each): 1.29 -- the dispatcher hands out the ranges
+// front to back and replaces every workgroup that finishes, which balances better than resident workgroups do (the hardware
+// favours a CU's oldest waves), the same way a one-element-per-thread copy (6.26 TB/s) beats every persistent copy (5.5-5.65).
+int decode_grid_for(mnw_ctx* c, int64_t tiles) {
+    if (c->grid_cap > 0) return (int)(tiles < c->grid_cap ? (tiles > 0 ? tiles : 1) : c->grid_cap);
+    int64_t per = tiles / ((int64_t)c->cus * 8);
+    per = per < 1 ? 1 : (per > 4 ? 4 : per);
+    const int64_t g = (tiles + per - 1) / per;
+    return (int)(g < 1 ? 1 : (g > 0x3fffffff ? 0x3fffffff : g));
 }
 
 int grid_for(mnw_ctx* c, int64_t tiles) {
@@ -1069,7 +1085,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
         const int j0 = cls_begin[cls], j1 = cls_begin[cls + 1];
         if (j1 == j0) continue;
         int64_t tiles = sl->h_jobs[j1 - 1].tile0 + (sl->h_jobs[j1 - 1].n + mnw::kTileD - 1) / mnw::kTileD;
-        const int grid = grid_for(c, tiles);
+        const int grid = decode_grid_for(c, tiles);
         if (cls < 2) { ScopedTimer t(c, s, MNW_K_UNPACK_F32); mnw::launch_unpack_f32(s, grid, cls == 0, sl->d_jobs + j0, j1 - j0, tiles); }
         else { ScopedTimer t(c, s, MNW_K_UNPACK_I64); mnw::launch_unpack_i64(s, grid, sl->d_jobs + j0, j1 - j0, tiles); }
     }
@@ -1357,10 +1373,89 @@ int mnw_minh_unlog(mnw_ctx* c, mnw_stream_t stream, const mnw_minh_col* cols, in
 
 // ---- text catalogue ingest (go/text/text.go:176-197, go/text/parse.go) --------------------------------
 namespace {
-constexpr unsigned kTextSlowCap = 1u << 20;
+constexpr unsigned kTextSlowCap0 = 1u << 16;      // first size of the list of literals left to the host; it grows on demand
 
 bool go_is_space(uint8_t ch) {      // unicode.IsSpace for the Latin-1 range, as bytes.Fields sees single bytes
     return ch == ' ' || (ch >= '\t' && ch <= '\r') || ch == 0x85 || ch == 0xA0;
+}
+
+// strconv.ParseFloat(tok, 64) for the literals the device leaves alone (Go 1.16, strconv/atof.go: special, readFloat,
+// underscoreOK restated; the digits themselves go through strtod in the "C" locale, correctly rounded like ParseFloat).
+// 0: *out is the value, 2: syntax error, 3: value out of range (ErrRange: the reference panics on both).
+int go_parse_float(const std::string& tok, double* out) {
+    const char* s = tok.c_str();
+    const size_t n = tok.size();
+    auto lower = [](char ch) { return (char)(ch | 0x20); };
+    if (n == 0) return 2;
+    // special(): an optional sign only in front of inf / infinity, none in front of nan; the whole token must be consumed
+    {
+        size_t i = 0;
+        int sign = 1;
+        bool had_sign = false;
+        if (s[0] == '+' || s[0] == '-') { sign = s[0] == '-' ? -1 : 1; had_sign = true; i = 1; }
+        auto prefix = [&](const char* w) { size_t k = 0; while (w[k] && i + k < n && lower(s[i + k]) == w[k]) ++k; return k; };
+        if (i < n && lower(s[i]) == 'i') {
+            size_t k = prefix("infinity");
+            if (k > 3 && k < 8) k = 3;
+            if ((k == 3 || k == 8) && i + k == n) { *out = sign * INFINITY; return 0; }
+            return 2;
+        }
+        if (i < n && lower(s[i]) == 'n') {
+            if (!had_sign && prefix("nan") == 3 && n == 3) { *out = NAN; return 0; }
+            return 2;
+        }
+    }
+    // readFloat's grammar: sign, optional 0x, digits with at most one '.', optional exponent (e for decimal; p, mandatory, for
+    // hexadecimal) with an optional sign and at least one digit; '_' anywhere in between, judged by underscoreOK
+    size_t i = 0;
+    if (s[i] == '+' || s[i] == '-') ++i;
+    bool hex = false;
+    if (i + 2 < n && s[i] == '0' && lower(s[i + 1]) == 'x') { hex = true; i += 2; }
+    bool sawdot = false, sawdigits = false, sawexp = false, underscores = false;
+    for (; i < n; ++i) {
+        const char ch = s[i];
+        if (ch == '_') { underscores = true; continue; }
+        if (ch == '.') { if (sawdot) break; sawdot = true; continue; }
+        if ((ch >= '0' && ch <= '9') || (hex && lower(ch) >= 'a' && lower(ch) <= 'f')) { sawdigits = true; continue; }
+        break;
+    }
+    if (!sawdigits) return 2;
+    if (i < n && lower(s[i]) == (hex ? 'p' : 'e')) {
+        ++i;
+        if (i >= n) return 2;
+        if (s[i] == '+' || s[i] == '-') ++i;
+        if (i >= n || s[i] < '0' || s[i] > '9') return 2;
+        for (; i < n && ((s[i] >= '0' && s[i] <= '9') || s[i] == '_'); ++i) if (s[i] == '_') underscores = true;
+        sawexp = true;
+    }
+    if (i != n) return 2;
+    if (hex && !sawexp) return 2;
+    std::string digits = tok;
+    if (underscores) {
+        // underscoreOK: an underscore only between digits, or between the base prefix and a digit
+        char saw = '^';
+        size_t k = 0;
+        if (s[k] == '+' || s[k] == '-') ++k;
+        bool hx = false;
+        if (n - k >= 2 && s[k] == '0' && (lower(s[k + 1]) == 'b' || lower(s[k + 1]) == 'o' || lower(s[k + 1]) == 'x')) { hx = lower(s[k + 1]) == 'x'; k += 2; saw = '0'; }
+        for (; k < n; ++k) {
+            const char ch = s[k];
+            if ((ch >= '0' && ch <= '9') || (hx && lower(ch) >= 'a' && lower(ch) <= 'f')) { saw = '0'; continue; }
+            if (ch == '_') { if (saw != '0') return 2; saw = '_'; continue; }
+            if (saw == '_') return 2;
+            saw = '!';
+        }
+        if (saw == '_') return 2;
+        digits.clear();
+        for (char ch : tok) if (ch != '_') digits.push_back(ch);
+    }
+    static locale_t c_locale = newlocale(LC_ALL_MASK, "C", (locale_t)0);      // a host program may have set a comma-decimal locale
+    char* endp = nullptr;
+    const double v = c_locale ? strtod_l(digits.c_str(), &endp, c_locale) : strtod(digits.c_str(), &endp);
+    if (endp != digits.c_str() + digits.size()) return 2;
+    if (isinf(v)) return 3;
+    *out = v;
+    return 0;
 }
 }  // namespace
 
@@ -1376,7 +1471,7 @@ int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint
     if (rc) return rc;
     rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
     if (rc) return rc;
-    if (!c->d_tslow) HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap));
+    if (!c->d_tslow) { HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap0)); c->cap_tslow = kTextSlowCap0; }
     if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
     HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
     if (c->timing) HIPCHK(c, hipStreamSynchronize(s));      // an event recorded behind a pageable copy is stamped before the copy has finished
@@ -1408,6 +1503,74 @@ int mnw_text_rows(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, 
     return MNW_OK;
 }
 
+namespace {
+// One pass of k_text_parse over the block that is on the device (text_load) for one set of columns in which every field
+// appears at most once, then the literals the device left to the host.
+int text_parse_pass(mnw_ctx* c, hipStream_t s, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment, mnw::TextCols& cols,
+                    int64_t capacity_rows, int64_t* n_rows) {
+    mnw::TextState st;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        mnw::TextState st0;
+        memset(&st0, 0, sizeof st0);
+        st0.err_line = ~0ull;
+        st0.n_rows = c->text_res_rows; st0.n_lines = c->text_res_lines;
+        HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
+        {
+            ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
+            mnw::launch_text_parse(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
+                                   (mnw::TextSlow*)c->d_tslow, (unsigned)c->cap_tslow, (mnw::TextState*)c->d_tstate);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&st, c->d_tstate, sizeof st, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (st.n_slow <= c->cap_tslow) break;
+        // more literals for the host than the list holds (the kernel counted them all): a list of that size, and the pass again
+        if (attempt == 1) return fail(c, MNW_E_HIP, "text: the list of literals for the host overflowed twice");
+        HIPCHK(c, hipFree(c->d_tslow));
+        c->d_tslow = nullptr; c->cap_tslow = 0;
+        const size_t want = (size_t)st.n_slow + (size_t)st.n_slow / 8 + 1024;
+        if (hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * want) != hipSuccess) { (void)hipGetLastError(); return fail(c, MNW_E_NOMEM, "text: no memory for the list of literals outside the device's fast path"); }
+        c->cap_tslow = want;
+    }
+    c->text_stats[0] = st.n_lines; c->text_stats[1] = st.n_rows; c->text_stats[2] = st.tiles_general;
+    *n_rows = st.n_rows;
+    if (st.n_rows > capacity_rows || (st.flags & 1u)) return fail(c, MNW_E_CAPACITY, "text: more lines than capacity_rows");
+    if (st.err_line != ~0ull) {
+        char buf[200];
+        const long long line = (long long)(st.err_line >> 8);
+        const int code = (int)(st.err_line & 0xff);
+        if (code == 1) snprintf(buf, sizeof buf, "Data on line %lld does not have %d columns.", line, cols.fields_expected);   // parse.go:114-118
+        else snprintf(buf, sizeof buf, "line %lld: strconv.%s: invalid syntax or value out of range", line, code == 2 ? "Atoi" : "ParseFloat");
+        return fail(c, MNW_E_DOMAIN, buf);
+    }
+    // ---- literals the device left alone (more than 19 digits, subnormal or overflowing values, inf / nan, hex floats,
+    // digit separators): converted here with Go's rules, written back in one copy and one small launch
+    if (st.n_slow > 0) {
+        std::vector<mnw::TextSlow> sl(st.n_slow);
+        HIPCHK(c, hipMemcpy(sl.data(), c->d_tslow, sizeof(mnw::TextSlow) * st.n_slow, hipMemcpyDeviceToHost));
+        for (mnw::TextSlow& w : sl) {
+            const std::string tok((const char*)text + w.offset, (size_t)w.len);
+            double v = 0;
+            const int rc = go_parse_float(tok, &v);
+            if (rc) {
+                char buf[200];
+                snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": %s", tok.c_str(), rc == 3 ? "value out of range" : "invalid syntax");
+                return fail(c, MNW_E_DOMAIN, buf);
+            }
+            const float f = (float)v;                         // float32(x): beyond float32's range becomes +-Inf as in Go
+            uint32_t u;
+            memcpy(&u, &f, 4);
+            w.offset = (int64_t)u;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_tslow, sl.data(), sizeof(mnw::TextSlow) * st.n_slow, hipMemcpyHostToDevice, s));
+        mnw::launch_text_patch(s, (const mnw::TextSlow*)c->d_tslow, st.n_slow, cols);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(s));                   // (sl is pageable host memory the copy reads)
+    }
+    return MNW_OK;
+}
+}  // namespace
+
 int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment,
                    const int32_t* float_cols, int n_float, float* const* float_out,
                    const int32_t* int_cols, int n_int, int64_t* const* int_out, int64_t capacity_rows, int64_t* n_rows) {
@@ -1417,26 +1580,18 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
     if (sep == '\n' || comment == '\n') return fail(c, MNW_E_ARG, "text: the newline cannot be the separator or the comment character");
     *n_rows = 0;
     if (nbytes == 0) return MNW_OK;
-    mnw::TextCols cols;
-    memset(&cols, 0, sizeof cols);
-    for (int k = 0; k < mnw::kTextMaxCols; ++k) cols.slot[k] = -1;
-    cols.max_field = -1;
-    cols.n_float = n_float; cols.n_int = n_int;
-    for (int k = 0; k < n_float + n_int; ++k) {                      // output column k: the floats first, then the ints
+    int max_field = -1;
+    for (int k = 0; k < n_float + n_int; ++k) {
         const bool isf = k < n_float;
         const int32_t f = isf ? float_cols[k] : int_cols[k - n_float];
         if (f < 0 || f >= mnw::kTextMaxCols) return fail(c, MNW_E_ARG, "text: field numbers must be in 0..255");
-        if (cols.slot[f] != -1) return fail(c, MNW_E_ARG, "text: a field may be requested once");
-        void* const o = isf ? (void*)float_out[k] : (void*)int_out[k - n_float];
-        if (!o) return fail(c, MNW_E_ARG, "text: null output");
-        cols.slot[f] = (int16_t)k;
-        cols.out[k] = o;
-        if (f > cols.max_field) cols.max_field = f;
+        if (!(isf ? (void*)float_out[k] : (void*)int_out[k - n_float])) return fail(c, MNW_E_ARG, "text: null output");
+        if (f > max_field) max_field = f;
     }
     // bufLen = len(bytes.Fields(lines[0])) (parse.go:96): words of the first kept line, split at white space
+    int words = -1;
     {
         int64_t p = 0;
-        int words = -1;
         while (p <= nbytes && words < 0) {
             int64_t e = p;
             while (e < nbytes && text[e] != '\n') ++e;
@@ -1458,73 +1613,48 @@ int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep,
             c->text_res = nullptr;
             return MNW_OK;
         }
-        cols.fields_expected = (n_float + n_int) > 0 ? words : -1;   // parseInt64s / parseFloat32s return at once when they have no column (parse.go:83, 132)
-        if (cols.max_field >= words) {
+        if (max_field >= words) {
             char buf[160];
-            snprintf(buf, sizeof buf, "Data has %d columns, but column %d was requested.", words, cols.max_field);    // parse.go:98-103
+            snprintf(buf, sizeof buf, "Data has %d columns, but column %d was requested.", words, max_field);    // parse.go:98-103
             return fail(c, MNW_E_DOMAIN, buf);
         }
     }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
     int rc = text_load(c, text, nbytes, sep, comment, false);       // a no-op right after mnw_text_rows on the same buffer
     if (rc) return rc;
     c->text_res = nullptr;                                          // one use only: the caller may refill the same buffer with the next block
-    mnw::TextState st0;
-    memset(&st0, 0, sizeof st0);
-    st0.err_line = ~0ull;
-    st0.n_rows = c->text_res_rows; st0.n_lines = c->text_res_lines;
-    HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
-    const uint8_t* dtext = (const uint8_t*)c->d_text;
-    (void)tiles;
-    {
-        ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
-        mnw::launch_text_parse(s, dtext, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
-                               (mnw::TextSlow*)c->d_tslow, kTextSlowCap, (mnw::TextState*)c->d_tstate);
-    }
-    HIPCHK(c, hipGetLastError());
-    mnw::TextState st;
-    HIPCHK(c, hipMemcpyAsync(&st, c->d_tstate, sizeof st, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    c->text_stats[0] = st.n_lines; c->text_stats[1] = st.n_rows; c->text_stats[2] = st.tiles_general;
-    *n_rows = st.n_rows;
-    if (st.n_rows > capacity_rows || (st.flags & 1u)) return fail(c, MNW_E_CAPACITY, "text: more lines than capacity_rows");
-    if (st.err_line != ~0ull) {
-        char buf[200];
-        const long long line = (long long)(st.err_line >> 8);
-        const int code = (int)(st.err_line & 0xff);
-        if (code == 1) snprintf(buf, sizeof buf, "Data on line %lld does not have %d columns.", line, cols.fields_expected);   // parse.go:114-118
-        else snprintf(buf, sizeof buf, "line %lld: strconv.%s: invalid syntax or value out of range", line, code == 2 ? "Atoi" : "ParseFloat");
-        return fail(c, MNW_E_DOMAIN, buf);
-    }
-    // ---- literals the device left alone: strtod is correctly rounded like strconv.ParseFloat ---------------------
-    if (st.n_slow > kTextSlowCap) return fail(c, MNW_E_NOMEM, "text: too many literals outside the device's fast path");
-    if (st.n_slow > 0) {
-        std::vector<mnw::TextSlow> sl(st.n_slow);
-        HIPCHK(c, hipMemcpy(sl.data(), c->d_tslow, sizeof(mnw::TextSlow) * st.n_slow, hipMemcpyDeviceToHost));
-        for (const mnw::TextSlow& w : sl) {
-            std::string tok((const char*)text + w.offset, (size_t)w.len);
-            // Go: "inf", "+Inf", "infinity", "nan" in any case; strtod agrees, and also on hex floats with a 'p' exponent
-            char* endp = nullptr;
-            errno = 0;
-            const double v = strtod(tok.c_str(), &endp);
-            // ... but strtod also takes a hex mantissa without the 'p' exponent that ParseFloat insists on, and white space in front
-            const bool hex = tok.find('x') != std::string::npos || tok.find('X') != std::string::npos;
-            const bool hex_no_p = hex && tok.find('p') == std::string::npos && tok.find('P') == std::string::npos;
-            if (endp != tok.c_str() + tok.size() || tok.find('_') != std::string::npos || hex_no_p || isspace((unsigned char)tok[0])) {
-                char buf[200];
-                snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": invalid syntax", tok.c_str());
-                return fail(c, MNW_E_DOMAIN, buf);
-            }
-            if (isinf(v) && (tok.find('n') == std::string::npos && tok.find('N') == std::string::npos)) {
-                char buf[200];                                 // ParseFloat returns ErrRange, which the reference panics on
-                snprintf(buf, sizeof buf, "strconv.ParseFloat: parsing \"%.60s\": value out of range", tok.c_str());
-                return fail(c, MNW_E_DOMAIN, buf);
-            }
-            const float f = (float)v;                         // float32(x): beyond float32's range becomes +-Inf as in Go
-            HIPCHK(c, hipMemcpy(float_out[w.slot] + w.row, &f, sizeof f, hipMemcpyHostToDevice));
+    // The reference's Block fills every requested output, also when a column is asked for twice or both as []int64 and as
+    // []float32 (text.go:202-221 splits the request by type and parses each list on its own).  The kernel maps a field to one
+    // output, so the outputs are dealt into passes in each of which a field appears once: one pass for any ordinary request.
+    const int n_out = n_float + n_int;
+    std::vector<char> done((size_t)(n_out > 0 ? n_out : 1), 0);
+    int left = n_out;
+    bool first = true;
+    while (first || left > 0) {
+        first = false;
+        mnw::TextCols cols;
+        memset(&cols, 0, sizeof cols);
+        for (int k = 0; k < mnw::kTextMaxCols; ++k) cols.slot[k] = -1;
+        cols.max_field = -1;
+        // (the kernel numbers the float outputs first, then the int outputs)
+        std::vector<int> pick_f, pick_i;
+        for (int k = 0; k < n_out; ++k) {
+            if (done[k]) continue;
+            const bool isf = k < n_float;
+            const int32_t f = isf ? float_cols[k] : int_cols[k - n_float];
+            if (cols.slot[f] != -1) continue;                        // this field already has an output in this pass: next pass
+            cols.slot[f] = 0;                                         // (marks the field taken; the output number is set below)
+            (isf ? pick_f : pick_i).push_back(k);
+            done[k] = 1; --left;
         }
+        cols.n_float = (int)pick_f.size(); cols.n_int = (int)pick_i.size();
+        int o = 0;
+        for (int k : pick_f) { cols.slot[float_cols[k]] = (int16_t)o; cols.out[o] = (void*)float_out[k]; if (float_cols[k] > cols.max_field) cols.max_field = float_cols[k]; ++o; }
+        for (int k : pick_i) { cols.slot[int_cols[k - n_float]] = (int16_t)o; cols.out[o] = (void*)int_out[k - n_float]; if (int_cols[k - n_float] > cols.max_field) cols.max_field = int_cols[k - n_float]; ++o; }
+        cols.fields_expected = n_out > 0 ? words : -1;               // parseInt64s / parseFloat32s return at once when they have no column (parse.go:83, 132)
+        rc = text_parse_pass(c, s, text, nbytes, sep, comment, cols, capacity_rows, n_rows);
+        if (rc) return rc;
     }
     return MNW_OK;
 }

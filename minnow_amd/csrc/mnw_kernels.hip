@@ -105,6 +105,18 @@ __device__ __forceinline__ int find_job(const DevJob* jobs, int njobs, int64_t t
     return lo;
 }
 
+// The same, tried first at the position the tile would have if all jobs had as many tiles as the first (the usual case:
+// a column cut into equal blocks): two or three scalar loads instead of a binary search.  The decode kernels run tens of
+// thousands of short workgroups, each of which starts with this.
+template <int TILE>
+__device__ __forceinline__ int find_job_guess(const DevJob* jobs, int njobs, int64_t t) {
+    const int64_t per = (jobs[0].n + TILE - 1) / TILE;
+    const int64_t g = per > 0 ? t / per : 0;
+    const int j = (int)(g < njobs - 1 ? g : njobs - 1);
+    if (jobs[j].tile0 <= t && (j + 1 == njobs || t < jobs[j + 1].tile0)) return j;
+    return find_job(jobs, njobs, t);
+}
+
 __device__ __forceinline__ int64_t tiles_of(int64_t n) { return (n + kTile - 1) / kTile; }
 __device__ __forceinline__ int64_t tiles_of_d(int64_t n) { return (n + kTileD - 1) / kTileD; }
 
@@ -1780,7 +1792,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
-    int j = find_job(jobs, njobs, t0);
+    int j = find_job_guess<kTileD>(jobs, njobs, t0);
     int buf = 0;
 
     while (t0 < t1) {
@@ -1864,7 +1876,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_i64(const DevJob* __restric
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
-    int j = find_job(jobs, njobs, t0);
+    int j = find_job_guess<kTileD>(jobs, njobs, t0);
     int buf = 0;
 
     while (t0 < t1) {

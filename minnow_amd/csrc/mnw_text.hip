@@ -439,6 +439,15 @@ void launch_text_count(hipStream_t s, const uint8_t* text, int64_t n, uint8_t se
 void launch_text_scan(hipStream_t s, int64_t* tile_cnt, int64_t tiles, TextState* st) {
     hipLaunchKernelGGL(k_text_scan, dim3(1), dim3(1024), 0, s, tile_cnt, tiles, st);
 }
+// the host's conversions of the literals the device left alone, written into their columns: slow[i].offset holds the
+// float32 bit pattern (low 32 bits), row and slot as the parse kernel recorded them
+__global__ __launch_bounds__(256) void k_text_patch(const TextSlow* __restrict__ slow, unsigned int n, TextCols cols) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) static_cast<uint32_t*>(cols.out[slow[i].slot])[slow[i].row] = (uint32_t)slow[i].offset;
+}
+void launch_text_patch(hipStream_t s, const TextSlow* slow, unsigned n, const TextCols& cols) {
+    hipLaunchKernelGGL(k_text_patch, dim3((n + 255) / 256), dim3(256), 0, s, slow, n, cols);
+}
 void launch_text_parse(hipStream_t s, const uint8_t* text, int64_t n, uint8_t sep, uint8_t comm, const int64_t* tile_base, const TextCols& cols,
                        int64_t capacity, TextSlow* slow, unsigned slow_cap, TextState* st) {
     const int64_t tiles = (n + kTextTile - 1) / kTextTile;

@@ -27,6 +27,62 @@ MNW_TN double text_pow10(int k) {
     return t[k];
 }
 
+#include "mnw_pow10_table.h"
+
+MNW_TN void text_mul64(uint64_t a, uint64_t b, uint64_t* hi, uint64_t* lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *lo = a * b; *hi = __umul64hi(a, b);
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    *lo = (uint64_t)p; *hi = (uint64_t)(p >> 64);
+#endif
+}
+
+// m * 10^e10 (0 < m < 2^64) rounded to the nearest float64, ties to even -- what strconv.ParseFloat returns for a literal
+// with that mantissa and exponent -- or false when this function cannot decide (the caller then leaves the literal to the
+// host): exponents outside the table, results outside the normal range, and the rare products too close to a rounding
+// boundary.  Interval form of the Eisel-Lemire method: with T = the 128 leading bits of 10^e10, truncated (10^e10 =
+// (T + eps) 2^(k-127), 0 <= eps < 1, eps == 0 exactly for 0 <= e10 <= 55) and mn = m shifted to 64 significant bits, the
+// 192-bit integer P = mn * T brackets the value: V / 2^(k-127-lz) lies in [P, P + mn), and equals P when T is exact.  The
+// 53-bit result is decided where every point of that interval rounds the same way; since mn < 2^64 lies far below the 138
+// or 139 bits that are rounded away, that fails only if those bits are within mn of the half-way point from below.
+MNW_TN bool text_scale10(uint64_t m, int e10, double* out) {
+    if (e10 < MNW_POW10_EMIN || e10 > MNW_POW10_EMAX) return false;
+    const uint64_t tab[MNW_POW10_EMAX - MNW_POW10_EMIN + 1][2] = MNW_POW10_TABLE;
+    const uint64_t th = tab[e10 - MNW_POW10_EMIN][0], tl = tab[e10 - MNW_POW10_EMIN][1];
+    const int k = (e10 * 217706) >> 16;                    // floor(log2(10^e10)) on this range (tools/gen_pow10_table.py asserts it)
+    const int lz = __builtin_clzll(m);
+    const uint64_t mn = m << lz;
+    uint64_t ah, al, bh, bl;
+    text_mul64(mn, th, &ah, &al);
+    text_mul64(mn, tl, &bh, &bl);
+    const uint64_t p0 = bl, p1 = al + bh;
+    const uint64_t p2 = ah + (p1 < al ? 1u : 0u);          // P = p2 2^128 + p1 2^64 + p0, 2^190 <= P < 2^192
+    const int top = (int)(p2 >> 63);                       // P's leading bit is bit 190 + top
+    const int sh = 10 + top;                               // bits of p2 below the 53 kept ones
+    uint64_t q = p2 >> sh;
+    const uint64_t rt = p2 & ((1ull << sh) - 1), hb = 1ull << (sh - 1);
+    bool up;
+    if (e10 >= 0 && e10 <= MNW_POW10_EXACT_MAX) {          // V == P: ordinary round to nearest even
+        const bool above = rt > hb || (rt == hb && (p1 | p0) != 0), tie = rt == hb && (p1 | p0) == 0;
+        up = above || (tie && (q & 1u));
+    } else if (rt >= hb) up = true;                        // P is at or above half and V lies strictly above P
+    else {
+        // below half: stays below unless the discarded bits are within mn of it
+        if (rt == hb - 1 && p1 == ~0ull && p0 + mn < p0) return false;
+        up = false;
+    }
+    q += up ? 1u : 0u;
+    int be = 63 + top + k - lz + 1023;                     // biased exponent of a 53-bit mantissa with its top bit set
+    if (q >> 53) { q >>= 1; be += 1; }
+    if (be < 1 || be > 2046) return false;                 // subnormal, zero, overflow: the host decides
+    const uint64_t bits = ((uint64_t)be << 52) | (q & 0x000fffffffffffffull);
+    double v;
+    __builtin_memcpy(&v, &bits, 8);
+    *out = v;
+    return true;
+}
+
 // Both general conversions are single loops over the token without early exits: every character updates a few state
 // words and a verdict.  (An earlier form with break / continue / return inside the loops was compiled into code that
 // returned "syntax error" for every literal with an exponent when the token was read through a global pointer, while the
@@ -101,10 +157,17 @@ MNW_TN int text_atof(const uint8_t* p, int len, double* out) {
     e10 += eneg ? -ex : ex;
     double v;
     if (m == 0) v = 0.0;
-    else if (inexact || m >= (1ull << 53)) return 1;
-    else if (e10 >= 0 && e10 <= 22) v = MNW_DMUL((double)m, text_pow10(e10));
-    else if (e10 < 0 && e10 >= -22) v = MNW_DDIV((double)m, text_pow10(-e10));
-    else return 1;
+    else if (inexact) return 1;                            // more than 19 significant digits: the host decides
+    else {
+        // trailing zeros of the mantissa belong to the exponent ("2.500000000000000000e+02", numpy.savetxt's default
+        // '%.18e', is 25 * 10^1): five conditional divisions by constants
+#define MNW_STRIP0(P, K) { const uint64_t q_ = m / P; if (q_ * P == m) { m = q_; e10 += K; } }
+        MNW_STRIP0(10000000000000000ull, 16) MNW_STRIP0(100000000ull, 8) MNW_STRIP0(10000ull, 4) MNW_STRIP0(100ull, 2) MNW_STRIP0(10ull, 1)
+#undef MNW_STRIP0
+        if (m < (1ull << 53) && e10 >= 0 && e10 <= 22) v = MNW_DMUL((double)m, text_pow10(e10));         // Clinger: one exact operation
+        else if (m < (1ull << 53) && e10 < 0 && e10 >= -22) v = MNW_DDIV((double)m, text_pow10(-e10));
+        else if (!text_scale10(m, e10, &v)) return 1;      // 17-19 digits or a larger exponent: 128-bit power-of-ten table
+    }
     *out = neg ? -v : v;
     return 0;
 }

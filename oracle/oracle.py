@@ -32,9 +32,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        # MNW_ORACLE_LIB: another build of the same source (tests/test_sanitizers_cpu.py runs the golden tests against an
+        # AddressSanitizer + UBSan build)
+        path = os.environ.get("MNW_ORACLE_LIB") or _LIB_PATH
+        if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         i64, u64, p, f32, dbl, ci = C.c_int64, C.c_uint64, C.c_void_p, C.c_float, C.c_double, C.c_int
         sigs = {
             "mnwo_precision_needed": (i64, [u64]),
@@ -362,6 +365,59 @@ def go_pow(x, y):
 
 
 # ---- text catalogue ingest (go/text/text.go:176-197, go/text/parse.go) ---------------------------------
+_GO_FLOAT = None
+
+
+def go_parse_float(tok):
+    """strconv.ParseFloat(tok, 64) (Go 1.16, strconv/atof.go restated: special(), readFloat's grammar, underscoreOK); the value
+    of a well-formed literal is the correctly rounded float64, which Python's float() / float.fromhex() return as well.
+    Raises ValueError where ParseFloat returns an error (the reference panics on it).  Parity unpinned beyond the reference's
+    own TestReader vector: there is no Go toolchain here."""
+    import re
+    global _GO_FLOAT
+    if _GO_FLOAT is None:
+        _GO_FLOAT = (re.compile(r"[+-]?(inf|infinity)$", re.I), re.compile(r"nan$", re.I),
+                     re.compile(r"[+-]?(?=[0-9_]*[0-9]|[0-9_]*\.[0-9_]*[0-9])[0-9_]*\.?[0-9_]*([eE][+-]?[0-9][0-9_]*)?$"),
+                     re.compile(r"[+-]?0[xX](?=[0-9a-fA-F_]*[0-9a-fA-F]|[0-9a-fA-F_]*\.[0-9a-fA-F_]*[0-9a-fA-F])[0-9a-fA-F_]*\.?[0-9a-fA-F_]*[pP][+-]?[0-9][0-9_]*$"))
+    inf_re, nan_re, dec_re, hex_re = _GO_FLOAT
+    bad = ValueError("strconv.ParseFloat: parsing %r: invalid syntax" % tok)
+    if inf_re.match(tok):
+        return -math.inf if tok[0] == "-" else math.inf
+    if nan_re.match(tok):                                   # no sign in front of nan (special() only lets one through for inf)
+        return math.nan
+    is_hex = bool(hex_re.match(tok))
+    if not is_hex and not dec_re.match(tok):
+        raise bad
+    if "_" in tok:
+        # underscoreOK: an underscore only between digits, or between the base prefix and a digit
+        t = tok[1:] if tok[0] in "+-" else tok
+        saw, i = "^", 0
+        if len(t) >= 2 and t[0] == "0" and t[1].lower() in "box":
+            i, saw = 2, "0"
+        digits = "0123456789abcdefABCDEF" if is_hex else "0123456789"
+        for ch in t[i:]:
+            if ch in digits:
+                saw = "0"
+            elif ch == "_":
+                if saw != "0":
+                    raise bad
+                saw = "_"
+            else:
+                if saw == "_":
+                    raise bad
+                saw = "!"
+        if saw == "_":
+            raise bad
+        tok = tok.replace("_", "")
+    try:
+        x = float.fromhex(tok) if is_hex else float(tok)
+    except OverflowError:
+        x = math.inf
+    if math.isinf(x):                                        # ErrRange, which the reference panics on
+        raise ValueError("strconv.ParseFloat: parsing %r: value out of range" % tok)
+    return x
+
+
 def text_block_parse(data, sep, comm, float_cols, int_cols):
     """text.Reader.Block after the read, restated: split at '\\n' (parse.go:15-36), uncomment (43-63), trim (66-78),
     fields (172-211), strconv.Atoi / float32(strconv.ParseFloat(s, 64)).  Python's int() and float() stand in for Atoi
@@ -387,11 +443,7 @@ def text_block_parse(data, sep, comm, float_cols, int_cols):
             raise ValueError("Data on line %d has %d columns, not %d." % (i + 1, len(words), buf_len))
         for k, c in enumerate(float_cols):
             tok = words[c].decode("ascii")
-            if "_" in tok or tok != tok.strip():                  # Python's float() takes digit separators and white space; ParseFloat does not
-                raise ValueError("strconv.ParseFloat: parsing %r: invalid syntax" % tok)
-            x = float(tok)
-            if math.isinf(x) and "n" not in tok.lower():          # ErrRange, which the reference panics on ("inf" / "infinity" are values)
-                raise ValueError("strconv.ParseFloat: parsing %r: value out of range" % tok)
+            x = go_parse_float(tok)
             with np.errstate(over="ignore"):                       # float32(x) beyond float32's range is +-Inf in Go too
                 fout[k][i] = np.float32(x)
         for k, c in enumerate(int_cols):

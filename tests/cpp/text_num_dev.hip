@@ -1,6 +1,6 @@
-// Device check of minnow_amd/csrc/mnw_text_num.h: every token of argv[1] (one per line) through text_atof / fast_atof16 /
+// Device check (run by tests/test_text_gpu.py::test_number_conversions_on_the_device) of minnow_amd/csrc/mnw_text_num.h: every token of argv[1] (one per line) through text_atof / fast_atof16 /
 // text_atoi / fast_atoi16 on the GPU, from global memory and from LDS, printed beside the host's results of the same source.
-// hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/microbench/text_num_dev.hip -o tools/microbench/text_num_dev
+// hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tests/cpp/text_num_dev.hip -o tests/cpp/text_num_dev
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>

@@ -21,8 +21,13 @@ INT_FORMS = [lambda r: str(int(r.integers(-10**18, 10**18))), lambda r: str(int(
 FLOAT_FORMS = [lambda r: "%.4e" % (10 ** r.uniform(8, 15)), lambda r: "%.5f" % r.uniform(0, 250), lambda r: "%.2f" % r.normal(0, 300),
                lambda r: "%g" % r.normal(0, 1e-3), lambda r: "%.17g" % (r.normal() * 10.0 ** int(r.integers(-40, 40))),
                lambda r: "%d" % int(r.integers(-10**6, 10**6)), lambda r: "%.12f" % r.uniform(-1, 1), lambda r: "%d.%020d" % (int(r.integers(0, 99)), int(r.integers(0, 10**18))),
-               lambda r: str(r.choice(["inf", "-Inf", "+infinity", "nan", "NaN", "1e22", "1e23", "1E5", ".5", "5.", "-0", "0", "1e-45", "4.9e-324", "16777217"]))]
-BAD_TOKENS = ["x", "1x", "--1", "1e", "1e+", "1..2", "1.2.3", "e5", "1_000", "0x10", "", "+", "1e999", "99999999999999999999", "1.5", "abc", "1e5"]
+               lambda r: str(r.choice(["inf", "-Inf", "+infinity", "nan", "NaN", "1e22", "1e23", "1E5", ".5", "5.", "-0", "0", "1e-45", "4.9e-324", "16777217",
+                                       "1_000", "0x1p-2", "1_2.5e0_1"])),
+               # numpy.savetxt's default format (19 significant digits, trailing zeros) and repr(): the device's 128-bit table path
+               lambda r: "%.18e" % (r.normal() * 10.0 ** int(r.integers(-30, 30))), lambda r: "%.18e" % round(r.normal(0, 250), 2),
+               lambda r: repr(float(r.normal() * 10.0 ** int(r.integers(-300, 300)))),
+               lambda r: "%de%d" % (int(r.integers(10**16, 10**19, dtype=np.uint64)), int(r.integers(-320, 289)))]
+BAD_TOKENS = ["x", "1x", "--1", "1e", "1e+", "1..2", "1.2.3", "e5", "1__0", "0x10", "", "+", "1e999", "99999999999999999999", "1.5", "abc", "1e5", "+nan", "_1", "0x1.8"]
 
 
 def make_case(rng):
@@ -46,7 +51,7 @@ def make_case(rng):
         if r < 0.08:
             out.append(sep * int(rng.integers(0, 3)) + comm + " only a comment")
             continue
-        toks = [(INT_FORMS if kinds[k] == 0 else FLOAT_FORMS)[int(rng.integers(0, 5 if kinds[k] == 0 else 9))](rng) for k in range(ncol)]
+        toks = [(INT_FORMS if kinds[k] == 0 else FLOAT_FORMS)[int(rng.integers(0, len(INT_FORMS) if kinds[k] == 0 else len(FLOAT_FORMS)))](rng) for k in range(ncol)]
         runs = 1 if sep == "\t" and rng.random() < 0.5 else int(rng.integers(1, 4))
         ln = sep * int(rng.integers(0, 3)) + (sep * runs).join(toks) + sep * int(rng.integers(0, 3))
         if long_lines and rng.random() < 0.3:

@@ -286,3 +286,75 @@ def test_block_beyond_4_gib(mnw, oracle, torch_mod):
     assert np.array_equal(i[:at].reshape(reps - 1, 20000), np.broadcast_to(ri[0], (reps - 1, 20000)))
     assert i[at] == 7 and f[at] == np.float32(0.12345678901234567890123)
     assert np.array_equal(f[at + 1:].view(np.uint32), rf[0].view(np.uint32)) and np.array_equal(i[at + 1:], ri[0])
+
+
+def test_savetxt_default_format_catalogue(mnw, oracle, torch_mod):
+    """numpy.savetxt's default '%.18e' (19 significant digits, many of them trailing zeros) and repr()-style 17-digit literals:
+    converted on the device by the 128-bit power-of-ten table (mnw_text_num.h: text_scale10), bit-equal to ParseFloat's values"""
+    rng = np.random.default_rng(31)
+    n = 30000
+    a = rng.standard_normal(n) * 10.0 ** rng.integers(-20, 20, n)
+    b = np.round(rng.standard_normal(n) * 250.0, 2)              # short values printed long: "2.500000000000000000e+02"
+    lines = ["%d %.18e %.18e %r" % (i, a[i], b[i], float(a[i] * 3.0)) for i in range(n)]
+    data = ("\n".join(lines) + "\n").encode()
+    with mnw.Context(0) as c:
+        assert _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1, 2, 3], [0]) == n
+
+
+def test_more_host_literals_than_the_first_list_holds(mnw, oracle, torch_mod):
+    """more than 65,536 literals that only the host converts (25 digits each): the list grows and the pass is repeated"""
+    rng = np.random.default_rng(32)
+    n = 70000
+    lines = ["%d 0.%025d" % (i, int(rng.integers(0, 10**18)) * 10**7 + int(rng.integers(1, 10**7))) for i in range(n)]
+    data = ("\n".join(lines) + "\n").encode()
+    with mnw.Context(0) as c:
+        assert _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0]) == n
+        assert _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0]) == n      # and again with the grown list
+
+
+def test_field_requested_twice(mnw, oracle, torch_mod):
+    """text.Reader.Block fills every output it is given, also when a column is requested twice or both as []int64 and as
+    []float32 (go/text/text.go:202-221 parses the two lists independently)"""
+    rng = np.random.default_rng(33)
+    lines = ["%d %d %.4e %d" % (i, rng.integers(-10**6, 10**6), rng.standard_normal() * 1e9, rng.integers(0, 100)) for i in range(5000)]
+    data = ("\n".join(lines) + "\n").encode()
+    with mnw.Context(0) as c:
+        n, fo, io = _parse(mnw, torch_mod, c, data, ord(" "), ord("#"), [2, 1, 2, 2], [1, 3, 1])
+        rf, ri = oracle.text_block_parse(data, ord(" "), ord("#"), [2, 1, 2, 2], [1, 3, 1])
+        assert n == 5000
+        for a, b in zip(fo, rf):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(io, ri):
+            assert np.array_equal(a, b)
+
+
+def test_go_literal_rules_on_the_host_path(mnw, oracle, torch_mod):
+    """what strconv.ParseFloat takes and what it refuses among the literals the device hands to the host: a sign in front of
+    inf but not of nan, digit separators between digits only, hexadecimal floats with their mandatory p exponent"""
+    good = ["inf", "-Inf", "+INFINITY", "nan", "NaN", "1_000", "1_23.50_0_0e+1_2", "0x1p-2", "0x1.8p3", "0X_1FFFP-16", "-0x.8p1"]
+    data = "\n".join("%d %s" % (i, t) for i, t in enumerate(good)).encode()
+    with mnw.Context(0) as c:
+        assert _check(mnw, torch_mod, c, oracle, data, ord(" "), ord("#"), [1], [0]) == len(good)
+        for t in ["+nan", "-nan", "nan(1)", "infinit", "_1", "1_", "1__0", "1_.5", "0x1.8", "1e_5", "0x", "1e999", "-1e999"]:
+            with pytest.raises(mnw.MnwError) as e:
+                _parse(mnw, torch_mod, c, ("0 1.5\n1 %s\n" % t).encode(), ord(" "), ord("#"), [1], [0])
+            assert "ParseFloat" in str(e.value), (t, str(e.value))
+            with pytest.raises(ValueError):
+                oracle.go_parse_float(t)
+
+
+def test_number_conversions_on_the_device(mnw):
+    """minnow_amd/csrc/mnw_text_num.h compiled for the device, every token of tests/golden/text_num_tokens.txt read from global
+    memory and from LDS, against the host build of the same source (which tests/test_text_num_cpu.py pins to the correctly
+    rounded values).  Guards against the miscompilation DESIGN.md section 3.10 records: an earlier form of the conversion
+    loops rejected every literal with an exponent when the token was read through a global pointer."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "text_num_dev.hip")
+    exe = os.path.join(root, "tests", "cpp", "text_num_dev")
+    deps = [src, os.path.join(root, "minnow_amd", "csrc", "mnw_text_num.h"), os.path.join(root, "minnow_amd", "csrc", "mnw_pow10_table.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", src, "-o", exe])
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "text_num_tokens.txt")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -18,9 +18,12 @@ LIB = os.path.join(ROOT, "tests", "cpp", "libtext_num_harness.so")
 
 @pytest.fixture(scope="module")
 def tn():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB])
-    L = C.CDLL(LIB)
+    if os.environ.get("MNW_TEXT_NUM_LIB"):                  # another build of the same source (tests/test_sanitizers_cpu.py)
+        L = C.CDLL(os.environ["MNW_TEXT_NUM_LIB"])
+    else:
+        if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+            subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", SRC, "-o", LIB])
+        L = C.CDLL(LIB)
     for f in ("tn_atoi", "tn_fast_atoi"):
         getattr(L, f).argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int64)]
     for f in ("tn_atof", "tn_fast_atof"):
@@ -114,3 +117,62 @@ def test_int_literals(tn):
     for bits in range(1, 64):
         for v in rng.integers(-2**bits, 2**bits, 50):
             _check_int(tn, str(int(v)))
+
+
+def test_float_literals_beyond_clinger(tn):
+    """17-19 significant digits and exponents beyond 10^+-22 -- numpy.savetxt's default '%.18e', repr() of a float64, physical
+    constants -- are converted by the 128-bit power-of-ten table (text_scale10): when the function returns a value it is the
+    correctly rounded one (Python's float() is); it may only give up (rc 1: left to the host) on a literal whose value lies
+    within 2^-64 (relative) of a rounding boundary, which a random literal practically never does."""
+    rng = np.random.default_rng(29)
+    decided = total = 0
+
+    def chk(s):
+        nonlocal decided, total
+        total += 1
+        rc = _check_float(tn, s)
+        assert rc in (0, 1), s
+        decided += rc == 0
+
+    for s in ("1.000000000000000000e+00", "2.500000000000000000e+02", "0.30000000000000004", "1.7976931348623157e308", "2.2250738585072014e-308",
+              "9007199254740993", "9007199254740993e0", "9.007199254740993e15", "18446744073709551615", "1e23", "8.5e-310", "1e-320", "1e309",
+              "6.02214076e23", "6.62607015e-34", "1.380649e-23", "9999999999999999999", "1000000000000000000e-18", "123456789012345678e4",
+              "4.35e300", "7.2e-290", "1e308", "1e-307", "0.000000000000000000000000000001", "3.141592653589793238", "2.718281828459045235e0"):
+        chk(s)
+    # numpy.savetxt's default format, and repr()
+    for scale in (1.0, 1e12, 1e-9, 1e150, 1e-150, 250.0):
+        for v in rng.standard_normal(6000) * scale:
+            chk("%.18e" % v)
+            chk(repr(float(v)))
+            chk("%.16e" % v)
+    # random 17..19-digit mantissas against every exponent the table covers
+    for _ in range(60000):
+        nd = int(rng.integers(17, 20))
+        m = int(rng.integers(10 ** (nd - 1), min(10 ** nd, 2 ** 64 - 1), dtype=np.uint64))
+        e = int(rng.integers(-307 - nd + 1, 308 - nd + 1))          # value in [1e-307, 1e308): float64's normal range
+        chk("%de%d" % (m, e))
+    # short mantissas with large exponents
+    for _ in range(20000):
+        m = int(rng.integers(1, 10 ** 6))
+        e = int(rng.integers(-307, 302))
+        chk("%de%d" % (m, e))
+    # as close to a rounding boundary as 19 digits get: the decimal expansion of the midpoint of two neighbouring
+    # float64 values, cut to 19 digits (just below the midpoint) and the same plus one unit in the last digit (just above)
+    from decimal import Decimal, getcontext
+    getcontext().prec = 800
+    for v in np.abs(rng.standard_normal(4000)) * 10.0 ** rng.integers(-300, 300, size=4000):
+        v = float(v)
+        if not (1e-300 < v < 1e300):
+            continue
+        mid = (Decimal(v) + Decimal(float(np.nextafter(v, np.inf)))) / 2
+        sign, digits, exp = mid.as_tuple()
+        m19 = int("".join(map(str, digits[:19])))
+        e19 = exp + len(digits) - 19
+        chk("%de%d" % (m19, e19))
+        chk("%de%d" % (m19 + 1, e19))
+    assert decided > 0.9995 * total, (decided, total)
+    # subnormal results, zero and overflow are left to the host (rc 1), never decided wrongly
+    for s in ("1e-320", "8.5e-310", "4.9e-324", "1e309", "2e308", "123456789012345678e-340", "1e-400", "1e400"):
+        b = s.encode()
+        x = C.c_double()
+        assert tn.tn_atof(b, len(b), C.byref(x)) == 1, s
