@@ -12,7 +12,10 @@
 #include <ctype.h>
 #include <locale.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mnw {
@@ -112,6 +115,70 @@ struct JobSlot {
     bool in_flight = false;
 };
 
+// ---- host <-> device staging for the host-pointer entry points (what the cgo shim binds: Go slices, pageable memory) -----
+// A pageable hipMemcpy runs at 7-9 GB/s on this platform (the runtime stages it through small internal buffers, one thread).
+// Here the bytes go through library-owned PINNED buffers in chunks: a few host threads copy chunk k+1 from the caller's memory
+// into a pinned buffer while the DMA engine moves chunk k, and the way back mirrors it (SURVEY.md 8b "Ownership": sync calls
+// retain nothing of the caller's memory after they return; library-owned pinned host buffers).
+struct CopyPool {                  // a fixed set of threads that split one memcpy between them
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint8_t* dst = nullptr; const uint8_t* src = nullptr; size_t n = 0;
+    int parts = 0, next_part = 0, done_parts = 0;
+    uint64_t epoch = 0;
+    bool quit = false;
+    void part(int k) {
+        const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+        const size_t a = per * k, b = a + per < n ? a + per : n;
+        if (a < b) memcpy(dst + a, src + a, b - a);
+    }
+    void worker() {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_go.wait(lk, [&] { return quit || epoch != seen; });
+            if (quit) return;
+            seen = epoch;
+            while (next_part < parts) {
+                const int k = next_part++;
+                lk.unlock(); part(k); lk.lock();
+                if (++done_parts == parts) cv_done.notify_all();
+            }
+        }
+    }
+    void start(int threads) { for (int i = 0; i < threads; ++i) th.emplace_back([this] { worker(); }); }
+    void copy(void* d, const void* s2, size_t bytes) {
+        if (bytes < (1u << 20) || th.empty()) { memcpy(d, s2, bytes); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        dst = (uint8_t*)d; src = (const uint8_t*)s2; n = bytes;
+        parts = (int)th.size() + 1; next_part = 0; done_parts = 0; ++epoch;
+        cv_go.notify_all();
+        while (next_part < parts) {          // the calling thread takes parts too
+            const int k = next_part++;
+            lk.unlock(); part(k); lk.lock();
+            ++done_parts;
+        }
+        cv_done.wait(lk, [&] { return done_parts == parts; });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
+struct Stager {
+    static constexpr int kBufs = 4;
+    size_t chunk = 16u << 20;
+    uint8_t* pin[kBufs] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kBufs] = {nullptr, nullptr, nullptr, nullptr};
+    bool busy[kBufs] = {false, false, false, false};
+    int next = 0;
+    CopyPool* pool = nullptr;
+    bool ready = false;
+};
+
 struct mnw_ctx {
     int device = 0;
     int cus = 256;
@@ -127,6 +194,9 @@ struct mnw_ctx {
     JobSlot* pend = nullptr;      // slot of the pending async encode batch
 
     // staging for the host-pointer entry points
+    Stager stg;
+    int host_threads = 0;          // threads that copy between the caller's memory and the pinned buffers (0: min(8, cores))
+    int64_t stage_min = 4 << 20;   // transfers below this many bytes go through a plain hipMemcpy
     size_t cap_in = 0, cap_out = 0;
     void* d_in = nullptr;
     void* d_out = nullptr;
@@ -294,6 +364,89 @@ int ensure_dev(mnw_ctx* c, void** p, size_t* cap, size_t need) {
     size_t want = need + need / 4 + 256;
     HIPCHK(c, hipMalloc(p, want));
     *cap = want;
+    return MNW_OK;
+}
+
+int stager_init(mnw_ctx* c) {
+    Stager& g = c->stg;
+    if (g.ready) return MNW_OK;
+    for (int b = 0; b < Stager::kBufs; ++b) {
+        HIPCHK(c, hipHostMalloc((void**)&g.pin[b], g.chunk, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&g.ev[b], hipEventDisableTiming));
+    }
+    int t = c->host_threads;
+    if (t <= 0) { const unsigned hw = std::thread::hardware_concurrency(); t = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1); }
+    g.pool = new CopyPool();
+    g.pool->start(t - 1);
+    g.ready = true;
+    return MNW_OK;
+}
+
+void stager_free(mnw_ctx* c) {
+    Stager& g = c->stg;
+    delete g.pool; g.pool = nullptr;
+    for (int b = 0; b < Stager::kBufs; ++b) {
+        if (g.pin[b]) hipHostFree(g.pin[b]);
+        if (g.ev[b]) hipEventDestroy(g.ev[b]);
+        g.pin[b] = nullptr; g.ev[b] = nullptr;
+    }
+    g.ready = false;
+}
+
+// Host (pageable) -> device, enqueued on s.  When it returns every byte has left the caller's buffer (it sits in device
+// memory or in a pinned buffer whose DMA is queued on s): nothing of `src` is retained.
+int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t bytes) {
+    if (bytes == 0) return MNW_OK;
+    if ((int64_t)bytes < c->stage_min) {
+        HIPCHK(c, hipMemcpyAsync(dev_dst, src, bytes, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));       // (a pageable source: the runtime may still be reading it)
+        return MNW_OK;
+    }
+    int rc = stager_init(c);
+    if (rc) return rc;
+    Stager& g = c->stg;
+    for (size_t off = 0; off < bytes; off += g.chunk) {
+        const size_t len = bytes - off < g.chunk ? bytes - off : g.chunk;
+        const int b = g.next; g.next = (g.next + 1) % Stager::kBufs;
+        if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
+        g.pool->copy(g.pin[b], (const uint8_t*)src + off, len);
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)dev_dst + off, g.pin[b], len, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(g.ev[b], s));
+        g.busy[b] = true;
+    }
+    return MNW_OK;
+}
+
+// Device -> host (pageable), behind everything already enqueued on s; returns when the bytes are in `dst`.
+int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t bytes) {
+    if (bytes == 0) return MNW_OK;
+    if ((int64_t)bytes < c->stage_min) {
+        HIPCHK(c, hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return MNW_OK;
+    }
+    int rc = stager_init(c);
+    if (rc) return rc;
+    Stager& g = c->stg;
+    for (int b = 0; b < Stager::kBufs; ++b)
+        if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
+    const size_t nchunks = (bytes + g.chunk - 1) / g.chunk;
+    auto issue = [&](size_t k) -> hipError_t {
+        const size_t off = k * g.chunk, len = bytes - off < g.chunk ? bytes - off : g.chunk;
+        const int b = (int)(k % Stager::kBufs);
+        hipError_t e = hipMemcpyAsync(g.pin[b], (const uint8_t*)dev_src + off, len, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(g.ev[b], s);
+        return e;
+    };
+    for (size_t k = 0; k < nchunks && k < (size_t)Stager::kBufs; ++k) HIPCHK(c, issue(k));
+    for (size_t k = 0; k < nchunks; ++k) {
+        const size_t off = k * g.chunk, len = bytes - off < g.chunk ? bytes - off : g.chunk;
+        const int b = (int)(k % Stager::kBufs);
+        HIPCHK(c, hipEventSynchronize(g.ev[b]));
+        g.pool->copy((uint8_t*)dst + off, g.pin[b], len);
+        if (k + Stager::kBufs < nchunks) HIPCHK(c, issue(k + Stager::kBufs));
+    }
+    g.next = 0;
     return MNW_OK;
 }
 
@@ -784,6 +937,7 @@ int mnw_ctx_destroy(mnw_ctx* c) {
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (auto& sl : c->slots) { free_slot(sl); if (sl.consumed) hipEventDestroy(sl.consumed); }
     for (auto& sl : c->dslots) { free_slot(sl); if (sl.consumed) hipEventDestroy(sl.consumed); }
+    stager_free(c);
     if (c->d_in) hipFree(c->d_in);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_q) hipFree(c->d_q);
@@ -805,6 +959,8 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
+    if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
+    if (!strcmp(name, "stage_min_bytes")) { c->stage_min = value; return MNW_OK; }
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_weighted")) { c->reg_weighted = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_test_drop_item")) { c->reg_drop_item = value; return MNW_OK; }
@@ -1473,8 +1629,8 @@ int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint
     if (rc) return rc;
     if (!c->d_tslow) { HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap0)); c->cap_tslow = kTextSlowCap0; }
     if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
-    HIPCHK(c, hipMemcpyAsync(c->d_text, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
-    if (c->timing) HIPCHK(c, hipStreamSynchronize(s));      // an event recorded behind a pageable copy is stamped before the copy has finished
+    rc = copy_h2d(c, s, c->d_text, text, (size_t)nbytes);      // pinned, chunked, the host-side copy on several threads
+    if (rc) return rc;
     {
         ScopedTimer t(c, s, MNW_K_TEXT_LINES);
         mnw::launch_text_count(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (int64_t*)c->d_tile);
@@ -1676,7 +1832,8 @@ int mnw_copy_to_device(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
     if (!c || nbytes < 0 || (nbytes > 0 && (!dst || !src))) return fail(c, MNW_E_ARG, "copy_to_device: bad arguments");
     if (nbytes == 0) return MNW_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    int rc = copy_h2d(c, c->stream, dst, src, (size_t)nbytes);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MNW_OK;
 }
@@ -1684,9 +1841,7 @@ int mnw_copy_to_host(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
     if (!c || nbytes < 0 || (nbytes > 0 && (!dst || !src))) return fail(c, MNW_E_ARG, "copy_to_host: bad arguments");
     if (nbytes == 0) return MNW_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MNW_OK;
+    return copy_d2h(c, c->stream, dst, src, (size_t)nbytes);
 }
 
 // ---- GenericCut (scripts/text_to_minh.go:271-312) ------------------------------------------------------
@@ -1770,8 +1925,7 @@ int mnw_unpack_u64_dev(mnw_ctx* c, mnw_stream_t stream, const uint8_t* in, int64
 static int stage_in(mnw_ctx* c, const void* host, size_t bytes) {
     int rc = ensure_dev(c, &c->d_in, &c->cap_in, bytes + 16);
     if (rc) return rc;
-    if (bytes) HIPCHK(c, hipMemcpyAsync(c->d_in, host, bytes, hipMemcpyHostToDevice, c->stream));
-    return MNW_OK;
+    return copy_h2d(c, c->stream, c->d_in, host, bytes);
 }
 
 int mnw_pack_u64(mnw_ctx* c, const uint64_t* x, int64_t n, int bits, uint8_t* out, int64_t out_len) {
@@ -1788,9 +1942,7 @@ int mnw_pack_u64(mnw_ctx* c, const uint64_t* x, int64_t n, int bits, uint8_t* ou
     if (rc) return rc;
     rc = mnw_pack_u64_dev(c, c->stream, (const uint64_t*)c->d_in, n, bits, (uint8_t*)c->d_out, (int64_t)c->cap_out);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)out_len, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MNW_OK;
+    return copy_d2h(c, c->stream, out, c->d_out, (size_t)out_len);
 }
 
 // bit.ArrayBuffer.Bits (bit.go:151-159): PrecisionNeeded(max(x)), 0 when x is empty.  The max scan runs
@@ -1839,9 +1991,7 @@ int mnw_unpack_u64(mnw_ctx* c, const uint8_t* in, int64_t in_len, int bits, int6
     if (rc) return rc;
     rc = mnw_unpack_u64_dev(c, c->stream, (const uint8_t*)c->d_in, (int64_t)nb, bits, n, (uint64_t*)c->d_out);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MNW_OK;
+    return copy_d2h(c, c->stream, out, c->d_out, (size_t)n * 8);
 }
 
 static int encode_host(mnw_ctx* c, int kind, const void* x, int64_t n, float low, float high, int64_t pixels,
@@ -1870,8 +2020,7 @@ static int encode_host(mnw_ctx* c, int kind, const void* x, int64_t n, float low
     *out_len = m.nbytes;
     if (m.nbytes > 0) {
         if (!out) return fail(c, MNW_E_ARG, "encode: null output");
-        HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)m.nbytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return copy_d2h(c, c->stream, out, c->d_out, (size_t)m.nbytes);
     }
     return MNW_OK;
 }
@@ -1905,9 +2054,7 @@ static int decode_host(mnw_ctx* c, int kind, const uint8_t* in, int64_t in_len, 
     j.low = low; j.high = high; j.kind = kind; j.periodic = periodic; j.seed = seed; j.block = block;
     rc = mnw_decode_blocks(c, c->stream, &j, 1);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, (size_t)n * esz, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MNW_OK;
+    return copy_d2h(c, c->stream, out, c->d_out, (size_t)n * esz);
 }
 
 int mnw_int_decode(mnw_ctx* c, const uint8_t* in, int64_t in_len, int64_t min, int64_t bits, int64_t n, int64_t* out) {
@@ -1961,9 +2108,7 @@ int mnw_vectors_decode_host(mnw_ctx* c, const uint8_t* in, int64_t slot_bytes, c
     rc = mnw_vectors_decode(c, c->stream, (const uint8_t*)c->d_in, slot_bytes, meta, n_file, sub_cells, low, high, pixels, periodic, L, seed,
                             first_block, (float*)c->d_out);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(vec_out, c->d_out, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MNW_OK;
+    return copy_d2h(c, c->stream, vec_out, c->d_out, (size_t)n * 12);
 }
 
 }  // extern "C"
