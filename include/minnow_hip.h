@@ -344,7 +344,11 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels
  *        when the geometry allows (n_sub and n_file multiples of four); 0 = always gather into the staging
  *        buffer first and run the block encoder on that.
- * grid_cap: upper bound on workgroups per launch. */
+ * vec3_tiles_per_wg: minp vector kernels: 2,048-particle tiles per workgroup (default 4; 0 = persistent grids).
+ * host_threads: threads that copy between the caller's memory and the library's pinned buffers in the host-pointer entry
+ *        points (default min(8, cores / 2)); set before the first such call.  stage_min_bytes: transfers below this size
+ *        use a plain hipMemcpy (default 4 MiB).
+ * grid_cap: upper bound on workgroups per launch (decode launches: 0 = about four tiles per workgroup). */
 int mnw_set_option(mnw_ctx *ctx, const char *name, int64_t value);
 
 #ifdef __cplusplus
