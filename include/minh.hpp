@@ -10,7 +10,14 @@
 // Header-only, C++17, needs only the C ABI (include/minnow_hip.h).
 #pragma once
 
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "minnow.hpp"
 
@@ -92,6 +99,7 @@ class Writer {
 
     // Close, minh.go:151-156
     void Close() {
+        writer_.drain();                                           // the blocks' file writes run on a thread of their own
         geometry g{l_, boundary_, (int64_t)cells_};
         f_->Header(g);
         const int64_t blocks = blocks_;
@@ -173,31 +181,118 @@ class Writer {
         break;
         }
 
-        // ---- the file, column after column as the reference writes it: one group per (block, column) ------------
-        size_t k = 0;
-        for (size_t i = 0; i < cols_.size(); ++i) {
-            const Column& c = cols_[i];
-            if (detail::isFixed(c.Type)) {
-                f_->FixedSizeGroup(c.Type, N);
-                const size_t nb = (size_t)N * (size_t)minnow::fixedSizeBytes[c.Type];
-                if (onDevice) {
-                    host_.resize(nb);
-                    minnow::detail::check(mnw_copy_to_host(ctx, host_.data(), cols[i], (int64_t)nb));
-                    f_->DataRaw(host_.data(), (size_t)N);
-                } else {
-                    f_->DataRaw(cols[i], (size_t)N);
-                }
-                continue;
+        // ---- everything the file needs of this block comes back in ONE pipelined transfer (the streams of all codec columns,
+        // and the fixed-size columns of a device block) into a buffer that the file-writing thread then owns
+        auto hb = std::make_shared<minnow::detail::RawBuf>();
+        std::vector<size_t> hostAt(cols_.size(), 0), hostLen(cols_.size(), 0);
+        {
+            size_t tot = 0, k = 0;
+            for (size_t i = 0; i < cols_.size(); ++i) {
+                const Column& c = cols_[i];
+                if (detail::isFixed(c.Type)) hostLen[i] = onDevice ? (size_t)N * (size_t)minnow::fixedSizeBytes[c.Type] : 0;
+                else hostLen[i] = (size_t)meta[k++].nbytes;
+                hostAt[i] = tot;
+                tot += (hostLen[i] + 63) & ~(size_t)63;
             }
-            if (c.Type == Int) f_->IntGroup(N);
-            else f_->FloatGroup(N, c.Low, c.High, c.Dx);
-            const mnw_block_meta& m = meta[k];
-            host_.resize((size_t)m.nbytes);
-            minnow::detail::check(mnw_copy_to_host(ctx, host_.data(), dstreams + slotAt[k], m.nbytes));
-            f_->DataEncoded(host_.data(), (size_t)m.nbytes, m.min, m.bits);
-            ++k;
+            if (!spare_.empty()) { hb = spare_.back(); spare_.pop_back(); }       // a buffer the writer thread has finished with
+            uint8_t* const hbase = hb->get(tot);
+            std::vector<void*> d;
+            std::vector<const void*> sptr;
+            std::vector<int64_t> nb;
+            k = 0;
+            for (size_t i = 0; i < cols_.size(); ++i) {
+                const bool fixed = detail::isFixed(cols_[i].Type);
+                const void* from = fixed ? cols[i] : (const void*)(dstreams + slotAt[k]);
+                if (!fixed) ++k;
+                if (hostLen[i] == 0) continue;
+                d.push_back(hbase + hostAt[i]); sptr.push_back(from); nb.push_back((int64_t)hostLen[i]);
+            }
+            if (!d.empty()) minnow::detail::check(mnw_copy_to_host_batch(ctx, (int)d.size(), d.data(), sptr.data(), nb.data()));
         }
+        // ---- the file, column after column as the reference writes it: one group per (block, column).  The writes run on
+        // the writer thread, in block order, while the caller prepares the next block (host arrays of a host block are
+        // written before Block returns: the caller may reuse them).
+        std::vector<const void*> hostCols = cols;
+        std::vector<mnw_block_meta> metaCopy = meta;
+        auto task = [this, hb, hostAt, hostLen, hostCols, metaCopy, N, onDevice]() {
+            size_t k = 0;
+            for (size_t i = 0; i < cols_.size(); ++i) {
+                const Column& c = cols_[i];
+                if (detail::isFixed(c.Type)) {
+                    f_->FixedSizeGroup(c.Type, N);
+                    f_->DataRaw(onDevice ? (const void*)(hb->p.get() + hostAt[i]) : hostCols[i], (size_t)N);
+                    continue;
+                }
+                if (c.Type == Int) f_->IntGroup(N);
+                else f_->FloatGroup(N, c.Low, c.High, c.Dx);
+                const mnw_block_meta& m = metaCopy[k++];
+                f_->DataEncoded(hb->p.get() + hostAt[i], (size_t)m.nbytes, m.min, m.bits);
+            }
+        };
+        bool hasHostFixed = false;
+        for (const Column& c : cols_) hasHostFixed = hasHostFixed || (detail::isFixed(c.Type) && !onDevice);
+        writer_.post(task, [this, hb]() { spare_.push_back(hb); });
+        if (hasHostFixed) writer_.drain();              // the task reads the caller's arrays
     }
+
+    // One thread that performs the file writes of the blocks in order, so that the writes of block b overlap the upload,
+    // parse and encode of block b+1 (minnow::Writer itself is single threaded: only this thread touches it between
+    // Header/Geometry and Close).  `done` callbacks run on the posting thread, in drain() / post().
+    struct FileWriter {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv, cv_idle;
+        std::deque<std::pair<std::function<void()>, std::function<void()>>> q;
+        std::vector<std::function<void()>> finished;
+        std::exception_ptr err;
+        bool quit = false, busy = false;
+        void run() {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [&] { return quit || !q.empty(); });
+                if (q.empty()) return;
+                auto t = std::move(q.front());
+                q.pop_front();
+                busy = true;
+                lk.unlock();
+                try { t.first(); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+                lk.lock();
+                busy = false;
+                finished.push_back(std::move(t.second));
+                cv_idle.notify_all();
+            }
+        }
+        void reap(std::unique_lock<std::mutex>& lk) {
+            std::vector<std::function<void()>> f;
+            f.swap(finished);
+            const std::exception_ptr e = err;
+            err = nullptr;
+            lk.unlock();
+            for (auto& fn : f) fn();
+            if (e) std::rethrow_exception(e);
+            lk.lock();
+        }
+        void post(std::function<void()> task, std::function<void()> done) {
+            std::unique_lock<std::mutex> lk(mu);
+            if (!th.joinable()) th = std::thread([this] { run(); });
+            cv_idle.wait(lk, [&] { return q.size() < 2; });          // at most two blocks of output in flight
+            reap(lk);
+            q.emplace_back(std::move(task), std::move(done));
+            cv.notify_all();
+        }
+        void drain() {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_idle.wait(lk, [&] { return q.empty() && !busy; });
+            reap(lk);
+        }
+        ~FileWriter() {
+            { std::lock_guard<std::mutex> g(mu); quit = true; }
+            cv.notify_all();
+            if (th.joinable()) th.join();
+        }
+    };
+    FileWriter writer_;
+    std::vector<std::shared_ptr<minnow::detail::RawBuf>> spare_;
 
     std::unique_ptr<minnow::Writer> f_;
     int blocks_ = 0;
@@ -342,13 +437,13 @@ class Reader {
         }
         if (codec.empty()) return;
         // the streams of the requested columns: file -> one staging buffer -> device, then one batch of decode jobs
-        host_.resize(total + 1);
+        uint8_t* const hraw = rawHost_.get(total + 1);
         for (const Item& it : codec) {
             std::fseek(f_->File(), (long)f_->BlockFileOffset(it.idx), SEEK_SET);
-            minnow::detail::fread_all(f_->File(), host_.data() + it.off, it.nbytes);
+            minnow::detail::fread_all(f_->File(), hraw + it.off, it.nbytes);
         }
         uint8_t* dstage = stage_.get(total + 64);
-        minnow::detail::check(mnw_copy_to_device(ctx, dstage, host_.data(), (int64_t)total));
+        minnow::detail::check(mnw_copy_to_device(ctx, dstage, hraw, (int64_t)total));
         uint8_t* dout = onDevice ? nullptr : outs_.get(codec.size() * detail::align16(N * esz));
         std::vector<mnw_dec_job> jobs;
         for (size_t k = 0; k < codec.size(); ++k) {
@@ -396,6 +491,7 @@ class Reader {
     int64_t fileType_ = basicFileType;
     detail::DevBuf stage_, outs_;
     std::vector<uint8_t> host_;
+    minnow::detail::RawBuf rawHost_;
 };
 inline std::unique_ptr<Reader> Open(const std::string& fname) { return std::make_unique<Reader>(fname); }       // minh.go:184
 

@@ -66,6 +66,16 @@ inline mnw_ctx* ctx() {
 inline void check(int rc) {
     if (rc != MNW_OK) throw Error(std::string(mnw_strerror(rc)) + ": " + mnw_last_error(ctx()), rc);
 }
+// grow-only host buffer whose bytes are NOT zeroed when it grows (a std::vector<uint8_t> writes every new byte once, a second
+// pass over hundreds of megabytes that are about to be overwritten by a copy from the device)
+struct RawBuf {
+    std::unique_ptr<uint8_t[]> p;
+    size_t cap = 0;
+    uint8_t* get(size_t n) {
+        if (n > cap) { const size_t want = n + n / 8 + 64; p.reset(new uint8_t[want]); cap = want; }
+        return p.get();
+    }
+};
 inline void fwrite_all(std::FILE* f, const void* p, size_t n) {
     if (n && std::fwrite(p, 1, n, f) != n) throw Error("write failed");
 }

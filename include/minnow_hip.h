@@ -261,6 +261,9 @@ int mnw_dev_alloc(mnw_ctx *ctx, int64_t nbytes, void **dev_ptr);
 int mnw_dev_free(mnw_ctx *ctx, void *dev_ptr);
 int mnw_copy_to_device(mnw_ctx *ctx, void *dev_dst, const void *host_src, int64_t nbytes);
 int mnw_copy_to_host(mnw_ctx *ctx, void *host_dst, const void *dev_src, int64_t nbytes);
+/* n device -> host copies as one pipelined transfer through the library's pinned buffers (the streams of all columns of a
+ * minh block, the blocks of a minp file): host_dst[i] receives nbytes[i] bytes from dev_src[i].  Synchronous. */
+int mnw_copy_to_host_batch(mnw_ctx *ctx, int n, void *const *host_dst, const void *const *dev_src, const int64_t *nbytes);
 
 /* ---- GenericCut of the reference's text_to_minh (scripts/text_to_minh.go:271-312) ----------------------------
  * Keeps, in order and in every column, the rows i with mass[i] > cutoff (ok[i] = m[i] > cutoff; filterFloat32 /

@@ -129,13 +129,24 @@ class Writer {
             minnow::detail::check(rc);
             break;
         }
+        // all 3 * subCells^3 streams come back in one pipelined transfer
+        const size_t nb = (size_t)(3 * subCells3);
+        std::vector<size_t> at(nb + 1, 0);
+        for (size_t b = 0; b < nb; ++b) at[b + 1] = at[b] + (((size_t)meta[b].nbytes + 63) & ~(size_t)63);
+        uint8_t* const hraw = raw_.get(at[nb] + 64);
+        {
+            std::vector<void*> d(nb);
+            std::vector<const void*> sp(nb);
+            std::vector<int64_t> len(nb);
+            for (size_t b = 0; b < nb; ++b) { d[b] = hraw + at[b]; sp[b] = dst + b * slot; len[b] = meta[b].nbytes; }
+            minnow::detail::check(mnw_copy_to_host_batch(ctx, (int)nb, d.data(), sp.data(), len.data()));
+        }
         for (int k = 0; k < 3; ++k) {                                  // file order: one FloatGroup per component, a block per sub-cell
             f_->FloatGroup((int)nSub3, mn[k], mx[k], dx_);
             for (int64_t sc = 0; sc < subCells3; ++sc) {
-                const mnw_block_meta& m = meta[(size_t)(k * subCells3 + sc)];
-                host_.resize((size_t)m.nbytes);
-                minnow::detail::check(mnw_copy_to_host(ctx, host_.data(), dst + (size_t)(k * subCells3 + sc) * slot, m.nbytes));
-                f_->DataEncoded(host_.data(), (size_t)m.nbytes, m.min, m.bits);
+                const size_t b = (size_t)(k * subCells3 + sc);
+                const mnw_block_meta& m = meta[b];
+                f_->DataEncoded(hraw + at[b], (size_t)m.nbytes, m.min, m.bits);
             }
         }
     }
@@ -150,6 +161,7 @@ class Writer {
     float dx_ = 0;
     detail::DevBuf grid_, streams_;
     std::vector<uint8_t> host_;
+    minnow::detail::RawBuf raw_;
 };
 inline std::unique_ptr<Writer> Create(const std::string& fname) { return std::make_unique<Writer>(fname); }
 
@@ -218,13 +230,14 @@ class Reader {
                 slot = std::max(slot, detail::align16((size_t)m.nbytes + 16));
             }
         }
-        host_.assign(slot * (size_t)(3 * subCells3), 0);
+        const size_t hostBytes = slot * (size_t)(3 * subCells3);
+        uint8_t* const hsrc = rawR_.get(hostBytes + 64);
         for (int64_t b = 0; b < 3 * subCells3; ++b) {
             std::fseek(f_->File(), (long)f_->BlockFileOffset((int)b), SEEK_SET);
-            minnow::detail::fread_all(f_->File(), host_.data() + (size_t)b * slot, (size_t)meta[(size_t)b].nbytes);
+            minnow::detail::fread_all(f_->File(), hsrc + (size_t)b * slot, (size_t)meta[(size_t)b].nbytes);
         }
-        uint8_t* dsrc = streams_.get(host_.size() + 16);
-        minnow::detail::check(mnw_copy_to_device(ctx, dsrc, host_.data(), (int64_t)host_.size()));
+        uint8_t* dsrc = streams_.get(hostBytes + 16);
+        minnow::detail::check(mnw_copy_to_device(ctx, dsrc, hsrc, (int64_t)hostBytes));
         minnow::detail::check(mnw_vectors_decode(ctx, nullptr, dsrc, (int64_t)slot, meta.data(), nFile, subCells, low, high, pixels,
                                                  Periodic ? 1 : 0, (float)Header.L, DitherSeed, 0, dout));
         uint8_t one;                                                     // a copy on the context's stream = wait for the decode
@@ -251,6 +264,7 @@ class Reader {
     Cell c_;
     detail::DevBuf grid_, streams_;
     std::vector<uint8_t> host_;
+    minnow::detail::RawBuf rawR_;
 };
 inline std::unique_ptr<Reader> Open(const std::string& fname) { return std::make_unique<Reader>(fname); }
 

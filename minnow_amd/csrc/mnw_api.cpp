@@ -12,6 +12,7 @@
 #include <ctype.h>
 #include <locale.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -417,6 +418,52 @@ int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t b
         HIPCHK(c, hipEventRecord(g.ev[b], s));
         g.busy[b] = true;
     }
+    return MNW_OK;
+}
+
+// n device -> host copies, pipelined through the pinned ring: every pinned chunk is filled by as many pieces as fit, the DMA of
+// chunk k+1 .. k+3 runs while the host threads copy chunk k out to the callers' buffers.
+int copy_d2h_batch(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const void* const* src, const int64_t* len) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)len[i];
+    if (total == 0) return MNW_OK;
+    int rc = stager_init(c);
+    if (rc) return rc;
+    Stager& g = c->stg;
+    for (int b = 0; b < Stager::kBufs; ++b)
+        if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
+    struct Piece { int item; size_t off, len, at; };
+    std::vector<std::vector<Piece>> chunks;                  // the pieces of every pinned chunk
+    {
+        std::vector<Piece> cur;
+        size_t fill = 0;
+        for (int i = 0; i < n; ++i) {
+            size_t off = 0;
+            while (off < (size_t)len[i]) {
+                const size_t take = std::min((size_t)len[i] - off, g.chunk - fill);
+                cur.push_back(Piece{i, off, take, fill});
+                off += take; fill += take;
+                if (fill == g.chunk) { chunks.push_back(cur); cur.clear(); fill = 0; }
+            }
+        }
+        if (!cur.empty()) chunks.push_back(cur);
+    }
+    auto issue = [&](size_t k) -> hipError_t {
+        const int b = (int)(k % Stager::kBufs);
+        for (const Piece& p : chunks[k]) {
+            const hipError_t e = hipMemcpyAsync(g.pin[b] + p.at, (const uint8_t*)src[p.item] + p.off, p.len, hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) return e;
+        }
+        return hipEventRecord(g.ev[b], s);
+    };
+    for (size_t k = 0; k < chunks.size() && k < (size_t)Stager::kBufs; ++k) HIPCHK(c, issue(k));
+    for (size_t k = 0; k < chunks.size(); ++k) {
+        const int b = (int)(k % Stager::kBufs);
+        HIPCHK(c, hipEventSynchronize(g.ev[b]));
+        for (const Piece& p : chunks[k]) g.pool->copy((uint8_t*)dst[p.item] + p.off, g.pin[b] + p.at, p.len);
+        if (k + Stager::kBufs < chunks.size()) HIPCHK(c, issue(k + Stager::kBufs));
+    }
+    g.next = 0;
     return MNW_OK;
 }
 
@@ -1846,6 +1893,14 @@ int mnw_copy_to_host(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
     if (nbytes == 0) return MNW_OK;
     HIPCHK(c, hipSetDevice(c->device));
     return copy_d2h(c, c->stream, dst, src, (size_t)nbytes);
+}
+
+int mnw_copy_to_host_batch(mnw_ctx* c, int n, void* const* dst, const void* const* src, const int64_t* nbytes) {
+    if (!c || n < 0 || (n > 0 && (!dst || !src || !nbytes))) return fail(c, MNW_E_ARG, "copy_to_host_batch: bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (nbytes[i] < 0 || (nbytes[i] > 0 && (!dst[i] || !src[i]))) return fail(c, MNW_E_ARG, "copy_to_host_batch: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    return copy_d2h_batch(c, c->stream, n, dst, src, nbytes);
 }
 
 // ---- GenericCut (scripts/text_to_minh.go:271-312) ------------------------------------------------------

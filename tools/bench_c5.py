@@ -16,6 +16,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--gen-only":        # write the catalog
     del sys.argv[1:3]
 rows = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2 * 10**6
 max_block = int(float(sys.argv[2])) if len(sys.argv) > 2 else 5 * 2**30
+repeat = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # the generated rows are written REPEAT times: a longer catalogue for the price of a short one
 from test_text_to_minh_gpu import _build
 exe = _build()
 rng = np.random.default_rng(3)
@@ -29,14 +30,19 @@ lines = cols[0]
 for c in cols[1:]:
     lines = np.char.add(np.char.add(lines, " "), c)
 names = ["id%d" % k for k in range(4)] + ["m%d" % k for k in range(20)] + ["x%d" % k for k in range(10)] + ["v%d" % k for k in range(10)]
-data = ("#" + " ".join(names) + "\n#a = 1.00000\n#synthetic catalogue\n" + "\n".join(lines.tolist()) + "\n").encode()
+head = ("#" + " ".join(names) + "\n#a = 1.00000\n#synthetic catalogue\n").encode()
+body = ("\n".join(lines.tolist()) + "\n").encode()
+data = head + body
 if gen_only:
     os.makedirs(gen_only, exist_ok=True)
     tmp = gen_only
 else:
     tmp = tempfile.mkdtemp(prefix="mnw_c5_")
 src, out = os.path.join(tmp, "hlist.txt"), os.path.join(tmp, "hlist.minh")
-open(src, "wb").write(data)
+with open(src, "wb") as fsrc:
+    fsrc.write(head)
+    for _ in range(repeat):
+        fsrc.write(body)
 spec = ["id%d:int" % k for k in range(4)] + ["m%d:log:1e8:1e16:0.01" % k for k in range(20)] + ["x%d:pos:0.001" % k for k in range(10)] + \
        ["v%d:lin:-5000:5000:1" % k for k in range(10)]
 cmd = [exe, src, out, "250", "m0", "3e8", str(max_block)] + spec
@@ -53,7 +59,7 @@ for rep in range(3):                                    # the file is in the pag
 rb = subprocess.run([exe, "--read", out], capture_output=True, text=True, timeout=1200)
 assert rb.returncode == 0, rb.stdout + rb.stderr
 best["read_back"] = json.loads(rb.stdout)
-best.update({"rows_generated": rows, "columns": 44, "bytes_per_row": len(data) / rows, "max_block_bytes": max_block})
+best.update({"rows_generated": rows, "repeat": repeat, "columns": 44, "bytes_per_row": len(body) / rows, "max_block_bytes": max_block})
 print(json.dumps(best))
 for f in (src, out):
     os.remove(f)
