@@ -1325,6 +1325,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         DevJob pjb;
         int pitems = 0;
         uint64_t sw[4];
+        u32x4 swa, swb;
         if (have_prev) {
             pjb = jobs[pj];
             pitems = (int)items_of(pjb.n);
@@ -1336,9 +1337,19 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                 first = (int)(pit - pjb.tile0) / kGroupItems * kGroupItems;
                 nload = pitems - first < kGroupItems ? pitems - first : kGroupItems;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                sw[k] = tid < nload ? __hip_atomic_load(&r0[first + tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
+            // Two 16-byte agent-scope loads per record, not four 8-byte ones: half as many requests on the record lines, which
+            // every workgroup of a block reads, and requests on one line are served one after the other (measured in one run,
+            // tools/ab_libs.sh: 1e9 elements in 2^20-element blocks 1,174 -> 1,121 us, 2^22-element blocks 178 -> 170 us per
+            // 1e8; one 16-byte load per lane -- lanes 2r, 2r+1 the halves of record r, one request per line -- was no better:
+            // 1,168 and 168 us, its parity-wise reduction costs what the requests save).  Issued here, waited for -- explicitly:
+            // the compiler does not see these loads -- where the fold below needs them.
+            swa = u32x4{0u, gen, 0u, gen}; swb = swa;
+            if (tid < nload) {
+                const MNW_GLOBAL ItemRec* rp = (const MNW_GLOBAL ItemRec*)(r0 + first + tid);
+                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1"
+                             : "+v"(swa), "+v"(swb) : "v"(rp) : "memory");
+            }
+            (void)neutral;
         }
 
         if (have_cur) {
@@ -1404,6 +1415,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         }
         if (have_prev) {
             // fold what the record loads brought
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(swa), "+v"(swb) :: "memory");
+            sw[0] = (uint64_t)swa.x | ((uint64_t)swa.y << 32); sw[1] = (uint64_t)swa.z | ((uint64_t)swa.w << 32);
+            sw[2] = (uint64_t)swb.x | ((uint64_t)swb.y << 32); sw[3] = (uint64_t)swb.z | ((uint64_t)swb.w << 32);
             uint32_t v[4] = {0, 0, 0, 0};
             uint32_t bad = 0, missing = 0;
 #pragma unroll 1
@@ -1419,9 +1433,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                 if (h == 1 || pitems <= kThreadsR || (BIG && pitems > kMaxSweep)) break;
                 const ItemRec* r1 = recs + pjb.tile0 + kThreadsR;
                 const uint64_t neutral = (uint64_t)gen << 32;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    sw[k] = tid + kThreadsR < pitems ? __hip_atomic_load(&r1[tid].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : neutral;
+                if (tid + kThreadsR < pitems) load_rec_sc1(r1 + tid, sw);
+                else { sw[0] = sw[1] = sw[2] = sw[3] = neutral; }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(v[k]);
