@@ -1018,6 +1018,17 @@ __device__ __forceinline__ uint64_t desc_from_sweep_f32(const DevJob& jb, int j,
     return gran_encode(d);
 }
 
+// One published record by two 16-byte agent-scope loads (each 8-byte word validates itself, so the halves need no
+// ordering); returns when the data is there.  Half the requests of four 8-byte loads: what a poll costs is the number of
+// requests that land on one line (they are served one after the other, about 2.5 ns each with a thousand pollers).
+__device__ __forceinline__ void load_rec_sc1(const ItemRec* p, uint64_t (&w)[4]) {
+    u32x4 a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"((const MNW_GLOBAL ItemRec*)p) : "memory");
+    w[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); w[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+}
+
 // wave 0 only, slow path: some record of the block was not there yet when the workgroup looked.  Polls
 // until all are present, then returns the descriptor word (0 on abort).
 __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __restrict__ jobs, int j,
@@ -1032,9 +1043,11 @@ __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __re
         uint32_t v[4] = {0, 0, 0, 0};
         uint32_t bad = 0, missing = 0;
         for (int r = lane_id(); r < nitems; r += 64) {
+            uint64_t w4[4];
+            load_rec_sc1(r0 + r, w4);                    // two 16-byte requests per record, not four 8-byte ones
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint64_t w = __hip_atomic_load(&r0[r].g[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t w = w4[k];
                 const uint32_t tag = (uint32_t)(w >> 32);
                 missing |= (tag & ~kRecBad) != gen;
                 bad |= tag & kRecBad;
@@ -1101,17 +1114,6 @@ __device__ unsigned long long g_big_diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cal
 #else
 #define MNW_BIG_DIAG(i, v)
 #endif
-// One published record by two 16-byte agent-scope loads (each 8-byte word validates itself, so the halves need no
-// ordering); returns when the data is there.  Half the requests of four 8-byte loads: what a poll costs is the number of
-// requests that land on one line (they are served one after the other, about 2.5 ns each with a thousand pollers).
-__device__ __forceinline__ void load_rec_sc1(const ItemRec* p, uint64_t (&w)[4]) {
-    u32x4 a, b;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"((const MNW_GLOBAL ItemRec*)p) : "memory");
-    w[0] = (uint64_t)a.x | ((uint64_t)a.y << 32); w[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
-    w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
-}
-
 // wave 0 only.  Large blocks, the two steps of the two-level sweep:
 //   group_duty_f32: poll the item records of the group of item `it` of job j until all are there, fold them and publish
 //      the group record.  Every member of a group does this (no leader; it waits for item records only), in the trip in
