@@ -260,3 +260,47 @@ def test_vectors_host_pointer_forms(mnw, oracle):
         assert rc == 0
     ref = oracle.minp_vectors_decode(blocks, nf, sub_cells, omn, omx, opix, True, L, seed=9, first_block=4)
     assert np.array_equal(back, ref)
+
+
+def test_c4_full_size_file_cell_vs_oracle(mnw, oracle, torch_mod):
+    """configs[3], one GPU's share at FULL size: one minp file cell of 500^3 = 1.25e8 particles, sub_cells = 5 -> 375 blocks of
+    1e6 per component (go/minp/minp.go:98-118), positions in a periodic box.  EVERY block against the oracle's Vectors (limits,
+    pixels, (min, bits, nbytes), stream bytes) and every decoded particle against the oracle's reader with the same dither."""
+    from minnow_amd import minp
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    nf, S, L, dx = 500, 5, 250.0, 0.001
+    n = nf ** 3
+    g = torch.Generator(device=dev); g.manual_seed(0xC4)
+    idx = torch.arange(n, device=dev)
+    pos = torch.stack([idx % nf, (idx // nf) % nf, idx // (nf * nf)], dim=1).to(torch.float32) * (L / nf)
+    del idx
+    pos.add_(torch.randn(pos.shape, device=dev, generator=g).mul_(2.0))
+    pos = torch.remainder(pos, L).contiguous()
+    pos[pos >= L] = 0.0
+    n_sub = nf // S
+    nb = 3 * S ** 3
+    slot = (4 * n_sub ** 3 + 15) // 16 * 16
+    packed = torch.zeros(nb * slot, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(pos)
+    torch.cuda.synchronize()
+    with mnw.Context(0) as c:
+        c.timing_enable(True)
+        metas, low, high, pixels = minp.vectors_encode(c, pos.data_ptr(), nf, S, dx, True, L, packed.data_ptr(), slot)
+        minp.vectors_decode(c, packed.data_ptr(), slot, metas, nf, S, low, high, pixels, True, L, out.data_ptr(), seed=5, first_block=2)
+        torch.cuda.synchronize()
+        ran = {k for k, v in c.timing_get().items() if v["launches"]}
+        assert {"k_reduce_vec3", "k_pack_vec3", "k_unpack_vec3"} <= ran, ran
+    vec = pos.cpu().numpy()
+    blocks, omn, omx, opix = oracle.minp_vectors_encode(vec, nf, S, dx, True, L)
+    assert np.array_equal(np.float32(low), omn) and np.array_equal(np.float32(high), omx) and list(pixels) == list(opix)
+    host = packed.cpu().numpy()
+    for b, (m, (omin, obits, odata)) in enumerate(zip(metas, blocks)):
+        assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), b
+        assert host[b * slot: b * slot + m.nbytes].tobytes() == odata.tobytes(), b
+    ref = oracle.minp_vectors_decode(blocks, nf, S, omn, omx, opix, True, L, seed=5, first_block=2)
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    d = np.abs(got.astype(np.float64) - vec.astype(np.float64))
+    d = np.minimum(d, L - d)
+    assert d.max() <= dx * 1.01 + 1e-4

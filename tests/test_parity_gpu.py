@@ -932,3 +932,119 @@ def test_headline_1e9_sampled_blocks_vs_oracle(mnw, oracle, torch_mod):
     nblk = (N + B - 1) // B
     blocks = sorted(set(range(0, nblk, 16)) | {0, nblk - 1})
     assert _headline_check(mnw, oracle, torch_mod, N, B, blocks) == 954
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configurations at FULL size (round 2): the launches bench.py and the tools time, checked against the oracle
+# ------------------------------------------------------------------------------------------------
+def test_c3_full_size_catalogue_sampled_blocks(mnw, oracle, torch_mod):
+    """configs[2] at its full row count: 28 codec columns x 1e8 rows (3 positions, 3 velocities, 18 logarithm-like float columns,
+    4 int columns; the 4 fixed-size columns of the shape are raw copies), one group per (2^20-row block, column) as
+    minh.Writer.Block lays them out, 16 row blocks per call.  Every 131st (block, column) pair -- and the last, ragged row
+    block of every column -- against the oracle: (min, bits, nbytes), stream bytes, decoded values."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rows, B = 10**8, 2**20
+    nblk = (rows + B - 1) // B
+    g = torch.Generator(device=dev); g.manual_seed(0xC3)
+    cols = []                                           # (kind, tensor, (low, high, dx) or None)
+    for c in range(3):
+        v = torch.remainder(torch.randn(rows, device=dev, generator=g) * 20 + 125, 250.0)
+        v[v >= 250.0] = 0.0
+        cols.append(("f", v, (0.0, 250.0, 0.001)))
+    for c in range(3):
+        cols.append(("f", torch.clamp(torch.randn(rows, device=dev, generator=g) * 300, -4999, 4999), (-5000.0, 5000.0, 1.0)))
+    for c in range(18):
+        cols.append(("f", torch.clamp(10 + c * 0.2 + 0.8 * torch.randn(rows, device=dev, generator=g), 8.001, 15.99), (8.0, 16.0, 0.01)))
+    cols.append(("i", torch.arange(rows, device=dev, dtype=torch.int64) + 5 * 10**9, None))
+    cols.append(("i", torch.poisson(torch.full((rows,), 40.0, device=dev), generator=g).to(torch.int64), None))
+    cols.append(("i", torch.randint(-1, 2**20, (rows,), device=dev, generator=g, dtype=torch.int64), None))
+    cols.append(("i", torch.full((rows,), 7, device=dev, dtype=torch.int64), None))
+    ncol = len(cols)
+    # stream slots: 4 B per element for the float columns (pixels < 2^32), 8 B for the int columns
+    slot = [(4 if k == "f" else 8) * B + 16 for k, _, _ in cols]
+    packed = [torch.zeros(nblk * s, dtype=torch.uint8, device=dev) for s in slot]
+    outs = [torch.empty_like(t) for _, t, _ in cols]
+    pix = [mnw.float_group_pixels(*lim) if lim else 0 for _, _, lim in cols]
+    metas = {}
+    torch.cuda.synchronize()                             # the context's stream is not ordered with torch's: the columns must be complete
+    with mnw.Context(0) as c2:
+        for b0 in range(0, nblk, 16):                    # 16 row blocks x 28 columns = one batch
+            jobs, keys = [], []
+            for b in range(b0, min(b0 + 16, nblk)):
+                n = min(B, rows - b * B)
+                for k, (kind, t, lim) in enumerate(cols):
+                    esz = 4 if kind == "f" else 8
+                    if kind == "f":
+                        jobs.append(mnw.EncJob(t.data_ptr() + esz * b * B, packed[k].data_ptr() + b * slot[k], n, slot[k], mnw.FLOAT_GROUP,
+                                               lim[0], lim[1], pix[k], 1))
+                    else:
+                        jobs.append(mnw.EncJob(t.data_ptr() + esz * b * B, packed[k].data_ptr() + b * slot[k], n, slot[k], mnw.INT_GROUP))
+                    keys.append((b, k))
+            for key, m in zip(keys, c2.encode_blocks(jobs)):
+                metas[key] = m
+        assert all(m.status == 0 for m in metas.values())
+        assert c2.counters()["single_read_aborts"] == 0
+        for b0 in range(0, nblk, 16):
+            djobs = []
+            for b in range(b0, min(b0 + 16, nblk)):
+                n = min(B, rows - b * B)
+                for k, (kind, t, lim) in enumerate(cols):
+                    m = metas[(b, k)]
+                    esz = 4 if kind == "f" else 8
+                    if kind == "f":
+                        djobs.append(mnw.DecJob(packed[k].data_ptr() + b * slot[k], outs[k].data_ptr() + esz * b * B, n, m.nbytes, m.min, m.bits,
+                                                mnw.FLOAT_GROUP, lim[0], lim[1], pix[k], 1, seed=11, block=b * ncol + k))
+                    else:
+                        djobs.append(mnw.DecJob(packed[k].data_ptr() + b * slot[k], outs[k].data_ptr() + esz * b * B, n, m.nbytes, m.min, m.bits,
+                                                mnw.INT_GROUP))
+            c2.decode_blocks(djobs)
+        torch.cuda.synchronize()
+    pairs = sorted(set([(b, k) for i, (b, k) in enumerate((b, k) for b in range(nblk) for k in range(ncol)) if i % 131 == 0] +
+                       [(nblk - 1, k) for k in range(ncol)]))
+
+    def one(bk):
+        b, k = bk
+        kind, t, lim = cols[k]
+        n = min(B, rows - b * B)
+        x = t[b * B: b * B + n].cpu().numpy()
+        m = metas[bk]
+        if kind == "f":
+            omin, obits, odata = oracle.float_encode(x, lim[0], lim[1], pix[k], True, literal=False)
+        else:
+            omin, obits, odata = oracle.int_encode(x, literal=False)
+        if (m.min, m.bits, m.nbytes) != (omin, obits, odata.size):
+            return "%r: (min, bits, nbytes) %r, oracle %r" % (bk, (m.min, m.bits, m.nbytes), (omin, obits, odata.size))
+        if packed[k][b * slot[k]: b * slot[k] + odata.size].cpu().numpy().tobytes() != odata.tobytes():
+            return "%r: stream differs" % (bk,)
+        y = outs[k][b * B: b * B + n].cpu().numpy()
+        if kind == "f":
+            want = oracle.float_decode(odata, omin, obits, lim[0], lim[1], pix[k], True, n, u=oracle.dither(11, b * ncol + k, n), literal=False)
+            if not np.array_equal(y.view(np.uint32), want.view(np.uint32)):
+                return "%r: decoded floats differ" % (bk,)
+        elif not np.array_equal(y, x):
+            return "%r: decoded ints differ" % (bk,)
+        return None
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        bad = [r for r in ex.map(one, pairs) if r]
+    assert not bad, bad[:5]
+    # and every float column as a whole: the reference's criterion (go/minnow_test.go:328-334)
+    for k, (kind, t, lim) in enumerate(cols):
+        if kind == "f":
+            d = (outs[k].double() - t.double()).abs()
+            if k < 3:
+                d = torch.minimum(d, 250.0 - d)
+            assert float(d.max()) <= lim[2] * 1.01 + 1e-3, k
+        else:
+            assert torch.equal(outs[k], t), k
+
+
+def test_1e9_column_in_2p24_blocks_sampled(mnw, oracle, torch_mod):
+    """The metric's column in SURVEY 8d C2's default block size: 60 blocks of 2^24 elements, read once by the large-block form of
+    the single-read kernel (one launch, asserted); every 7th block, the first and the ragged last one against the oracle."""
+    N, B = 10**9, 2**24
+    nblk = (N + B - 1) // B
+    blocks = sorted(set(range(0, nblk, 7)) | {0, nblk - 1})
+    assert _headline_check(mnw, oracle, torch_mod, N, B, blocks) == 60
