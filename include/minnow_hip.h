@@ -249,6 +249,12 @@ int mnw_text_parse(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t se
  * Synchronous. */
 int mnw_text_rows(mnw_ctx *ctx, const uint8_t *text, int64_t nbytes, uint8_t sep, uint8_t comment,
                   int64_t *n_lines, int64_t *n_rows);
+/* mnw_text_rows for a block whose bytes the caller has ALREADY copied to the device (text_dev; e.g. by mnw_copy_to_device on a
+ * second context and thread while the previous block was being parsed): no upload here.  text is the same block in host memory
+ * (the library looks at its first kept line and at the few literals the device leaves to the host); text_dev must stay
+ * untouched until the mnw_text_parse calls that follow have returned. */
+int mnw_text_rows_resident(mnw_ctx *ctx, const uint8_t *text, const uint8_t *text_dev, int64_t nbytes, uint8_t sep, uint8_t comment,
+                           int64_t *n_lines, int64_t *n_rows);
 /* Of the last mnw_text_parse: out[0] = lines (split()'s tokens), out[1] = lines kept, out[2] = 12 KB tiles of text that
  * took the general one-thread-per-line path (a comment character or an overlong line in reach) instead of the
  * one-thread-per-field path. */

@@ -14,6 +14,8 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <memory>
+#include <thread>
 #include "minnow.hpp"
 
 namespace text {
@@ -48,6 +50,10 @@ class Reader {
         findBlocks();
     }
     ~Reader() {
+        joinUpload();
+        pending_.reset();
+        for (void* p : upBuf_) if (p && upCtx_) mnw_dev_free(upCtx_, p);
+        if (upCtx_) mnw_ctx_destroy(upCtx_);
         Close();
         if (dev_) mnw_dev_free(minnow::detail::ctx(), dev_);
     }
@@ -85,12 +91,16 @@ class Reader {
         if (b < 0 || b >= Blocks()) throw Error("block index out of range");
         mnw_ctx* ctx = minnow::detail::ctx();
         // rd.buf: the block's bytes.  The reference reads them into a buffer (text.go:183-187); here the file's pages are
-        // mapped and go to the device straight from the page cache -- no copy on the host at all
-        const Mapped block(fileno(f_), blockStarts_[(size_t)b], blockSizes_[(size_t)b]);
-        const uint8_t* const text = block.data;
+        // mapped and go to the device straight from the page cache.  While block b is parsed (and the caller cuts, encodes and
+        // writes it), block b + 1 is already on its way: a second thread with a library context of its own maps it and copies
+        // it into the other of two device buffers (the reference's callers walk the blocks in order, text_to_minh.go:205).
+        std::unique_ptr<Upload> up = takeUpload(b);
+        if (b + 1 < Blocks() && blockSizes_[(size_t)b + 1] > 0) startUpload(b + 1);
+        const uint8_t* const text = up->block->data;
         const int64_t nbytes = blockSizes_[(size_t)b];
         int64_t lines = 0, rows = 0;
-        minnow::detail::check(mnw_text_rows(ctx, text, nbytes, config_.Separator, config_.Comment, &lines, &rows));
+        if (up->dev) minnow::detail::check(mnw_text_rows_resident(ctx, text, up->dev, nbytes, config_.Separator, config_.Comment, &lines, &rows));
+        else minnow::detail::check(mnw_text_rows(ctx, text, nbytes, config_.Separator, config_.Comment, &lines, &rows));
         // splitByType, text.go:202-221
         std::vector<int32_t> fIdx, iIdx;
         std::vector<size_t> fAt, iAt;
@@ -130,6 +140,64 @@ class Reader {
     }
 
    private:
+    struct Mapped;
+    // a block on its way to the device (or there): the mapping stays alive as long as the parse may look at the host bytes
+    struct Upload {
+        int b = -1;
+        std::unique_ptr<Mapped> block;
+        const uint8_t* dev = nullptr;                   // null: not uploaded (Block uploads it itself)
+        std::string err;
+    };
+    std::unique_ptr<Upload> takeUpload(int b) {
+        joinUpload();
+        std::unique_ptr<Upload> up;
+        if (pending_ && pending_->b == b) up = std::move(pending_);
+        pending_.reset();
+        if (up && !up->err.empty()) throw Error(up->err);
+        if (!up) {                                       // first block, or blocks asked for out of order: no prefetch to use
+            up.reset(new Upload());
+            up->b = b;
+            up->block.reset(new Mapped(fileno(f_), blockStarts_[(size_t)b], blockSizes_[(size_t)b]));
+        }
+        return up;
+    }
+    void joinUpload() { if (upThread_.joinable()) upThread_.join(); }
+    void startUpload(int b) {
+        joinUpload();
+        pending_.reset(new Upload());
+        Upload* up = pending_.get();
+        up->b = b;
+        const int fd = fileno(f_);
+        const int64_t off = blockStarts_[(size_t)b], len = blockSizes_[(size_t)b];
+        const int slot = upNext_;
+        upNext_ ^= 1;
+        upThread_ = std::thread([this, up, fd, off, len, slot] {
+            try {
+                up->block.reset(new Mapped(fd, off, len));
+                if (!upCtx_) {
+                    const char* dev = std::getenv("MNW_DEVICE");
+                    const int rc = mnw_ctx_create(dev ? std::atoi(dev) : 0, &upCtx_);
+                    if (rc != MNW_OK) { upCtx_ = nullptr; return; }          // no second context: Block uploads the block itself
+                }
+                if (upCap_[slot] < (size_t)len + 64) {
+                    if (upBuf_[slot]) mnw_dev_free(upCtx_, upBuf_[slot]);
+                    upBuf_[slot] = nullptr; upCap_[slot] = 0;
+                    const size_t want = (size_t)len + (size_t)len / 8 + 256;
+                    if (mnw_dev_alloc(upCtx_, (int64_t)want, &upBuf_[slot]) != MNW_OK) return;
+                    upCap_[slot] = want;
+                }
+                if (mnw_copy_to_device(upCtx_, upBuf_[slot], up->block->data, len) != MNW_OK) return;
+                up->dev = static_cast<const uint8_t*>(upBuf_[slot]);
+            } catch (const std::exception& e) { up->err = e.what(); }
+        });
+    }
+    std::unique_ptr<Upload> pending_;
+    std::thread upThread_;
+    mnw_ctx* upCtx_ = nullptr;
+    void* upBuf_[2] = {nullptr, nullptr};
+    size_t upCap_[2] = {0, 0};
+    int upNext_ = 0;
+
     struct Mapped {                                     // [offset, offset + len) of a file, read-only
         void* base = nullptr;
         size_t maplen = 0;

@@ -105,6 +105,7 @@ SIGNATURES = {
     "mnw_generic_cut": (_int, [_p, _p, _p, C.c_float, _i64, C.POINTER(CutColC), _int, C.POINTER(_i64)]),
     "mnw_text_rows": (_int, [_p, _p, _i64, C.c_uint8, C.c_uint8, C.POINTER(_i64), C.POINTER(_i64)]),
     "mnw_text_stats": (_int, [_p, C.POINTER(_i64)]),
+    "mnw_text_rows_resident": (_int, [_p, _p, _p, _i64, C.c_uint8, C.c_uint8, C.POINTER(_i64), C.POINTER(_i64)]),
     "mnw_timing_get": (_int, [_p, C.POINTER(KernelTimeC)]),
     "mnw_kernel_name": (C.c_char_p, [_int]),
     "mnw_counters_get": (_int, [_p, C.POINTER(_i64)]),

@@ -216,6 +216,7 @@ struct mnw_ctx {
     // text ingest scratch (grow-only): the text, line starts, kept-line flags, per-tile counts and bases, slow list
     size_t cap_text = 0, cap_tile = 0;
     void* d_text = nullptr; void* d_tile = nullptr;
+    const void* d_text_now = nullptr;               // where the resident block's bytes are: d_text, or a device buffer the caller uploaded (mnw_text_rows_resident)
     void* d_tslow = nullptr; void* d_tstate = nullptr;
     size_t cap_tslow = 0;                           // literals the slow list holds (grows when a block needs more)
     const uint8_t* text_res = nullptr;              // host text whose copy, tile counts and prefixes are on the device (mnw_text_rows)
@@ -1668,23 +1669,30 @@ int go_parse_float(const std::string& tok, double* out) {
 
 namespace {
 // the text on the device, lines / kept lines per tile counted and prefixed, totals on the host
-int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment, bool force) {
+int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment, bool force, const void* resident = nullptr) {
     if (!force && c->text_res == text && c->text_res_n == nbytes && c->text_res_sep == sep && c->text_res_comm == comment) return MNW_OK;
     c->text_res = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int64_t tiles = (nbytes + mnw::kTextTile - 1) / mnw::kTextTile;
-    int rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
-    if (rc) return rc;
+    int rc = MNW_OK;
+    if (!resident) {
+        rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
+        if (rc) return rc;
+    }
     rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
     if (rc) return rc;
     if (!c->d_tslow) { HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap0)); c->cap_tslow = kTextSlowCap0; }
     if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));
-    rc = copy_h2d(c, s, c->d_text, text, (size_t)nbytes);      // pinned, chunked, the host-side copy on several threads
-    if (rc) return rc;
+    if (resident) c->d_text_now = resident;                    // the caller has uploaded the block (another context, another stream)
+    else {
+        rc = copy_h2d(c, s, c->d_text, text, (size_t)nbytes);  // pinned, chunked, the host-side copy on several threads
+        if (rc) return rc;
+        c->d_text_now = c->d_text;
+    }
     {
         ScopedTimer t(c, s, MNW_K_TEXT_LINES);
-        mnw::launch_text_count(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (int64_t*)c->d_tile);
+        mnw::launch_text_count(s, (const uint8_t*)c->d_text_now, nbytes, sep, comment, (int64_t*)c->d_tile);
         mnw::launch_text_scan(s, (int64_t*)c->d_tile, tiles, (mnw::TextState*)c->d_tstate);
     }
     HIPCHK(c, hipGetLastError());
@@ -1724,7 +1732,7 @@ int text_parse_pass(mnw_ctx* c, hipStream_t s, const uint8_t* text, int64_t nbyt
         HIPCHK(c, hipMemcpyAsync(c->d_tstate, &st0, sizeof st0, hipMemcpyHostToDevice, s));
         {
             ScopedTimer t(c, s, MNW_K_TEXT_PARSE);
-            mnw::launch_text_parse(s, (const uint8_t*)c->d_text, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
+            mnw::launch_text_parse(s, (const uint8_t*)c->d_text_now, nbytes, sep, comment, (const int64_t*)c->d_tile, cols, capacity_rows,
                                    (mnw::TextSlow*)c->d_tslow, (unsigned)c->cap_tslow, (mnw::TextState*)c->d_tstate);
         }
         HIPCHK(c, hipGetLastError());
@@ -1777,6 +1785,20 @@ int text_parse_pass(mnw_ctx* c, hipStream_t s, const uint8_t* text, int64_t nbyt
     return MNW_OK;
 }
 }  // namespace
+
+int mnw_text_rows_resident(mnw_ctx* c, const uint8_t* text, const uint8_t* text_dev, int64_t nbytes, uint8_t sep, uint8_t comment,
+                           int64_t* n_lines, int64_t* n_rows) {
+    if (!c || nbytes < 0 || (nbytes > 0 && (!text || !text_dev))) return fail(c, MNW_E_ARG, "text: bad arguments");
+    if (sep == '\n' || comment == '\n') return fail(c, MNW_E_ARG, "text: the newline cannot be the separator or the comment character");
+    if (n_lines) *n_lines = nbytes == 0 ? 1 : 0;
+    if (n_rows) *n_rows = 0;
+    if (nbytes == 0) return MNW_OK;
+    const int rc = text_load(c, text, nbytes, sep, comment, true, text_dev);
+    if (rc) return rc;
+    if (n_lines) *n_lines = c->text_res_lines;
+    if (n_rows) *n_rows = c->text_res_rows;
+    return MNW_OK;
+}
 
 int mnw_text_parse(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint8_t comment,
                    const int32_t* float_cols, int n_float, float* const* float_out,
