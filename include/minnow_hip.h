@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNW_ABI_VERSION 3   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get */
+#define MNW_ABI_VERSION 4   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get; 4: MNW_K_COUNT 20 (k_encode_reg_i64) */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MNW_OK            0
@@ -315,7 +315,8 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_TEXT_LINES  16  /* text ingest: lines and kept lines per tile + prefix (k_text_count, k_text_scan) */
 #define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers (k_text_parse) */
 #define MNW_K_CUT         18  /* GenericCut: count + prefix, scatter */
-#define MNW_K_COUNT       19
+#define MNW_K_ENCODE_REG_I64 19 /* single-read int64 encode: the block is read once (k_encode_reg_i64) */
+#define MNW_K_COUNT       20
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;
@@ -335,6 +336,7 @@ const char *mnw_kernel_name(int kernel_id);
 #define MNW_C_TWO_PASS_BATCHES    2  /* float batches that went to the reduce + pack launches directly (not eligible / option) */
 #define MNW_C_EXACT_BLOCKS        3  /* float blocks sent to the exact sequential path (out-of-domain data) */
 #define MNW_C_FUSED_BATCHES       4  /* float batches encoded by the opt-in fused launch k_encode_f32 */
+#define MNW_C_INT_SINGLE_READ_BATCHES 5 /* batches whose int64 blocks were encoded by k_encode_reg_i64 (aborts count in MNW_C_SINGLE_READ_ABORTS) */
 #define MNW_C_COUNT               8
 int mnw_counters_get(mnw_ctx *ctx, int64_t out[MNW_C_COUNT]);
 int mnw_counters_reset(mnw_ctx *ctx);
@@ -345,6 +347,8 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * single_read: 1 (default) = a float batch whose blocks can all be held on chip -- at most 2^24 elements each on a
  *        whole MI355X (twice as many 8,192-element items as the launch has workgroups) -- is encoded by
  *        k_encode_reg_f32, which reads each block once; 0 = always the reduce + pack launches.
+ * single_read_int: 1 (default) = the int64 blocks of a batch, if each has at most 2^21 elements (512 items of 4,096), are
+ *        encoded by k_encode_reg_i64, which reads each block once; 0 = always k_reduce_i64 + k_pack_i64.
  * big_blocks: 1 (default) = that includes blocks of more than 2^22 elements; 0 = those take reduce + pack.
  * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
  *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.

@@ -29,6 +29,9 @@ void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
 void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int, int);
+void launch_encode_reg_i64(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t);
+int64_t reg_item_elems_i64();
+int encode_reg_i64_blocks_per_cu();
 size_t item_rec_bytes();
 int reg_max_items_per_block();
 int reg_max_items_per_big_block();
@@ -250,6 +253,10 @@ struct mnw_ctx {
     int big_blocks = 1;          // ... including blocks of more than 512 items (two-level record sweep), up to twice the grid
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
+    int reg_i64_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_i64 per CU
+    int single_read_int = 1;     // int64 encode through k_encode_reg_i64 whenever the batch's int blocks are eligible
+    bool pend_int_reg = false;   // the pending batch's int jobs went through k_encode_reg_i64
+    int pend_nslot = 0;          // device slots of the pending batch (float jobs, then int jobs)
     int pend_mode = 0;           // 0 two-kernel, 1 fused, 2 single read
     void* d_recs = nullptr;      // single read: one published statistics record per item (grow-only)
     size_t cap_recs = 0;
@@ -736,54 +743,86 @@ int stage_xforms(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat) {
     return MNW_OK;
 }
 
-// Single-read float encode (k_encode_reg_f32) for the float jobs [0, nfloat) of the slot.  Only legal
-// when every block has at most `grid` items (see the kernel's header); returns 1 if not eligible.
-int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all) {
+// Single-read encode: k_encode_reg_f32 for the float jobs [0, nfloat) of the slot and k_encode_reg_i64 for its int jobs
+// [nfloat, nslot_all), each only if every block of the kind fits the kernel's sweep (see the kernels' headers).
+// *did_float / *did_int say which were launched; the caller sends the other kind through reduce + pack afterwards
+// (its prepare_slot uploads the tables again, with the int jobs' item numbering unchanged).
+int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int nslot_all, bool want_float, bool* did_float, bool* did_int) {
+    *did_float = *did_int = false;
     if (c->reg_blocks_per_cu == 0) {
         int occ = mnw::encode_reg_f32_blocks_per_cu();
         c->reg_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);     // 256-thread workgroups, 36 KB LDS: four per CU
         occ = mnw::encode_reg_f32_xf_blocks_per_cu();
         c->reg_xf_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);  // the instantiation with the value transform (2.5 KB more LDS)
+        occ = mnw::encode_reg_i64_blocks_per_cu();
+        c->reg_i64_blocks_per_cu = occ < 1 ? -1 : (occ > 4 ? 4 : occ);
     }
     int any_xform = 0;
     for (int k = 0; k < nfloat; ++k) any_xform |= sl->h_jobs[k].xform;
     const int per_cu = any_xform ? c->reg_xf_blocks_per_cu : c->reg_blocks_per_cu;
-    if (per_cu < 1) return 1;
+    // ---- float jobs.  Blocks of at most min(G, 512) items: flat record sweep, weighted hand-out.  Larger ones, up to
+    // min(2 G, 4096) items (2^24 elements on a full grid of G = 1,024): two-level sweep; beyond G items the rounds must be
+    // unweighted (see "large blocks" in mnw_kernels.hip).  `big_blocks` = 0 keeps everything above 512 items on two passes.
+    const int64_t item = mnw::reg_item_elems();
     int grid = c->cus * per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
-    // Blocks of at most min(G, 512) items: flat record sweep, weighted hand-out.  Larger ones, up to min(2 G, 4096)
-    // items (2^24 elements on a full grid of G = 1,024): two-level sweep; beyond G items the rounds must be unweighted
-    // (see "large blocks" in mnw_kernels.hip).  `big_blocks` = 0 keeps everything above 512 items on the two-pass path.
-    const int64_t item = mnw::reg_item_elems();
     int64_t items = 0, groups = 0, max_ni = 0;
-    for (int k = 0; k < nfloat; ++k) {
-        const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
-        if (ni > max_ni) max_ni = ni;
-        items += ni;
-    }
-    if (items < grid) grid = items > 0 ? (int)items : 1;
-    {
+    bool fl = want_float && nfloat > 0 && per_cu >= 1;
+    if (fl) {
+        for (int k = 0; k < nfloat; ++k) {
+            const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
+            if (ni > max_ni) max_ni = ni;
+            items += ni;
+        }
+        if (items < grid) grid = items > 0 ? (int)items : 1;
         const int64_t flat = mnw::reg_max_items_per_block();
         int64_t lim = grid < flat ? grid : flat;
         if (c->big_blocks) {
             lim = 2 * (int64_t)grid;
             if (lim > mnw::reg_max_items_per_big_block()) lim = mnw::reg_max_items_per_big_block();
         }
-        if (max_ni > lim) return 1;
+        if (max_ni > lim) fl = false;
     }
+    if (!fl) items = 0;
+    // ---- int jobs: flat sweep only
+    const int64_t item_i = mnw::reg_item_elems_i64();
+    int grid_i = c->cus * c->reg_i64_blocks_per_cu;
+    if (c->grid_cap > 0 && c->grid_cap < grid_i) grid_i = c->grid_cap;
+    int64_t items_i = 0;
+    bool in = c->single_read_int && nslot_all > nfloat && c->reg_i64_blocks_per_cu >= 1;
+    if (in) {
+        int64_t mx = 0;
+        for (int k = nfloat; k < nslot_all; ++k) {
+            const int64_t ni = (sl->h_jobs[k].n + item_i - 1) / item_i;
+            if (ni > mx) mx = ni;
+            items_i += ni;
+        }
+        if (items_i < grid_i) grid_i = items_i > 0 ? (int)items_i : 1;
+        const int64_t flat = mnw::reg_max_items_per_block();
+        if (mx > (grid_i < flat ? grid_i : flat)) in = false;
+    }
+    if (!in) items_i = 0;
+    if (!fl && !in) return MNW_OK;
     const bool unweighted = max_ni > grid;
-    items = 0;
-    for (int k = 0; k < nfloat; ++k) {
-        const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
-        sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
-        sl->h_jobs[k].grp0 = groups;          // ... and its group records: R x R of them (R copies of R records), large blocks only
-        items += ni;
-        if (ni > mnw::reg_max_items_per_block()) {
-            const int64_t R = (ni + mnw::reg_group_items() - 1) / mnw::reg_group_items();
-            groups += R * R;
+    if (fl) {
+        items = 0;
+        for (int k = 0; k < nfloat; ++k) {
+            const int64_t ni = (sl->h_jobs[k].n + item - 1) / item;
+            sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
+            sl->h_jobs[k].grp0 = groups;          // ... and its group records: R x R of them (R copies of R records), large blocks only
+            items += ni;
+            if (ni > mnw::reg_max_items_per_block()) {
+                const int64_t R = (ni + mnw::reg_group_items() - 1) / mnw::reg_group_items();
+                groups += R * R;
+            }
         }
     }
-    const size_t need = (size_t)(items + groups) * mnw::item_rec_bytes();
+    const int64_t items_pad = (items + 3) / 4 * 4;       // the int launch's item table starts here
+    if (in) {
+        int64_t t = 0;
+        for (int k = nfloat; k < nslot_all; ++k) { sl->h_jobs[k].tile0 = t; t += (sl->h_jobs[k].n + item_i - 1) / item_i; }
+    }
+    const size_t need = (size_t)(items + groups + items_i) * mnw::item_rec_bytes();
     if (need > c->cap_recs) {
         // (re)allocation happens between batches only: the previous batch has been finished by then
         if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
@@ -793,11 +832,12 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         HIPCHK(c, hipMemsetAsync(c->d_recs, 0, want, s));      // tags of a fresh buffer must not match any generation
         c->cap_recs = want;
     }
-    if ((size_t)items > sl->cap_itemjob) {
+    const int64_t table_items = items_pad + items_i;
+    if ((size_t)table_items > sl->cap_itemjob) {
         // the slot is not in flight (acquire_slot waited for its previous batch)
         if (sl->d_itemjob) { hipFree(sl->d_itemjob); hipHostFree(sl->h_itemjob); }
         sl->d_itemjob = nullptr; sl->h_itemjob = nullptr; sl->cap_itemjob = 0;
-        const size_t want = ((size_t)items + (size_t)items / 2 + 1024 + 3) / 4 * 4;
+        const size_t want = ((size_t)table_items + (size_t)table_items / 2 + 1024 + 3) / 4 * 4;
         HIPCHK(c, hipMalloc((void**)&sl->d_itemjob, want * sizeof(int)));
         HIPCHK(c, hipHostMalloc((void**)&sl->h_itemjob, want * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
         sl->cap_itemjob = want;
@@ -805,25 +845,33 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
     }
     c->reg_gen = (c->reg_gen + 1) & 0x7fffffffu;
     if (c->reg_gen == 0) c->reg_gen = 1;
-    sl->h_sync[0] = 0;                        // the kernel raises it (pinned host word) if it gives up
-    // (int jobs of the same batch, slots [nfloat, nslot_all), go through the two-kernel path afterwards and need
-    // their statistics and synchronisation words zeroed; the float jobs here need neither)
-    const bool ints = nslot_all > nfloat;
-    const size_t table_bytes = sizeof(DevJob) * (size_t)nfloat;
-    if (ints || !tables_unchanged(sl, 2, table_bytes)) {
-        for (int k = 0; k < nfloat; ++k) {
-            const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
-            for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k;
-        }
+    sl->h_sync[0] = 0;                        // the kernels raise it (pinned host word) if they give up
+    // (jobs of the batch that do not go through these kernels take the two-kernel path afterwards and need their
+    // statistics and synchronisation words zeroed; the jobs here need neither)
+    const bool others = (nfloat > 0 && !fl) || (nslot_all > nfloat && !in);
+    const size_t table_bytes = sizeof(DevJob) * (size_t)nslot_all;
+    const int tag = in ? (fl ? 4 : 3) : 2;
+    if (others || !tables_unchanged(sl, tag, table_bytes)) {
+        if (fl)
+            for (int k = 0; k < nfloat; ++k) {
+                const int64_t i0 = sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item - 1) / item;
+                for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k;
+            }
+        for (int64_t i = items; i < items_pad; ++i) sl->h_itemjob[i] = 0;
+        if (in)
+            for (int k = nfloat; k < nslot_all; ++k) {
+                const int64_t i0 = items_pad + sl->h_jobs[k].tile0, ni = (sl->h_jobs[k].n + item_i - 1) / item_i;
+                for (int64_t i = 0; i < ni; ++i) sl->h_itemjob[i0 + i] = k - nfloat;     // relative to the int launch's job table
+            }
         // one small launch: job records and item table to device memory, abort word zeroed
         mnw::launch_prepare(s, sl->h_up, sl->d_up, (int64_t)sl->up_bytes,
-                            ints ? sl->d_stats : nullptr, ints ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot_all) : 0,
-                            sl->d_sync, (int64_t)(sizeof(uint32_t) * kSyncPad + (ints ? sl->sync_stride * nslot_all : 0)),
-                            sl->h_itemjob, sl->d_itemjob, ((int64_t)items * 4 + 15) / 16 * 16);
+                            others ? sl->d_stats : nullptr, others ? (int64_t)(sizeof(uint64_t) * mnw::kStatSlots * mnw::kStatWords * nslot_all) : 0,
+                            sl->d_sync, (int64_t)(sizeof(uint32_t) * kSyncPad + (others ? sl->sync_stride * nslot_all : 0)),
+                            sl->h_itemjob, sl->d_itemjob, ((int64_t)table_items * 4 + 15) / 16 * 16);
         HIPCHK(c, hipGetLastError());
-        if (ints) sl->shadow_tag = 0; else remember_tables(sl, 2, table_bytes);
+        if (others) sl->shadow_tag = 0; else remember_tables(sl, tag, table_bytes);
     }
-    if (items > 0) {
+    if (fl && items > 0) {
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_F32);
         // the weighted hand-out only when the grid is the full co-resident one (four workgroups on every CU) and no
         // block has more items than the grid has workgroups; group records live behind the item records
@@ -832,7 +880,14 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
                                    sl->d_meta, (grid == c->cus * 4 && !unweighted) ? c->reg_weighted : 0, c->reg_drop_item, any_xform,
                                    max_ni > mnw::reg_max_items_per_block() ? 1 : 0);
     }
+    if (in && items_i > 0) {
+        ScopedTimer t(c, s, MNW_K_ENCODE_REG_I64);
+        mnw::launch_encode_reg_i64(s, grid_i, sl->d_jobs + nfloat, nslot_all - nfloat, items_i, sl->d_itemjob + items_pad,
+                                   (uint8_t*)c->d_recs + (size_t)(items + groups) * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl),
+                                   sl->d_hsync, sl->d_meta + nfloat, grid_i == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item);
+    }
     HIPCHK(c, hipGetLastError());
+    *did_float = fl; *did_int = in;
     return MNW_OK;
 }
 
@@ -947,6 +1002,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_UNPACK_I64: return "k_unpack_i64";
         case MNW_K_ENCODE_F32: return "k_encode_f32";
         case MNW_K_ENCODE_REG_F32: return "k_encode_reg_f32";
+        case MNW_K_ENCODE_REG_I64: return "k_encode_reg_i64";
         case MNW_K_SUBCELL_GATHER: return "k_subcell_gather";
         case MNW_K_SUBCELL_SCATTER: return "k_subcell_scatter";
         case MNW_K_BOUNDS3: return "k_bounds3";
@@ -1009,6 +1065,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "group_bytes")) { c->group_bytes = value > 0 ? value : (1ll << 40); return MNW_OK; }
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
+    if (!strcmp(name, "single_read_int")) { c->single_read_int = value != 0; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_tiles_per_wg")) { c->vec3_tiles_per_wg = (int)value; return MNW_OK; }
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
@@ -1140,35 +1197,42 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
         c->pend_fused = fused;
         c->pend_nfloat = nfloat;
         c->pend_mode = fused ? 1 : 0;
-        rc = 1;
-        if (!fused && c->single_read && nfloat > 0) {
-            // keep the group-relative numbering in case the batch is not eligible
-            std::vector<int64_t> keep(nfloat);
-            for (int k = 0; k < nfloat; ++k) keep[k] = sl->h_jobs[k].tile0;
-            rc = launch_encode_reg(c, sl, s, nfloat, nslot);
-            if (rc == 1) for (int k = 0; k < nfloat; ++k) sl->h_jobs[k].tile0 = keep[k];
-            else if (rc == MNW_OK) { c->pend_mode = 2; c->counters[MNW_C_SINGLE_READ_BATCHES]++; }
-            else return rc;
+        c->pend_int_reg = false;
+        c->pend_nslot = nslot;
+        bool did_f = false, did_i = false;
+        if (!fused && ((c->single_read && nfloat > 0) || (c->single_read_int && nslot > nfloat))) {
+            // keep the group-relative numbering of what turns out not to be eligible
+            std::vector<int64_t> keep(nslot);
+            for (int k = 0; k < nslot; ++k) keep[k] = sl->h_jobs[k].tile0;
+            rc = launch_encode_reg(c, sl, s, nfloat, nslot, c->single_read != 0, &did_f, &did_i);
+            if (rc) return rc;
+            if (!did_f) for (int k = 0; k < nfloat; ++k) sl->h_jobs[k].tile0 = keep[k];
+            if (!did_i) for (int k = nfloat; k < nslot; ++k) sl->h_jobs[k].tile0 = keep[k];
+            if (did_f) { c->pend_mode = 2; c->counters[MNW_C_SINGLE_READ_BATCHES]++; }
+            if (did_i) { c->pend_int_reg = true; c->counters[MNW_C_INT_SINGLE_READ_BATCHES]++; }
         }
-        if (rc != MNW_OK) {
+        if (!did_f) {
             // not the single-read kernel: minh value transforms are applied in a pass of their own first
             int rs = stage_xforms(c, sl, s, nfloat);
             if (rs) return rs;
         }
-        if (rc == MNW_OK) {
+        rc = MNW_OK;
+        if (did_f) {
             // launched above
         } else if (fused) {
             c->counters[MNW_C_FUSED_BATCHES]++;
             rc = launch_encode_fused(c, sl, s, nfloat, nslot);        // its k_prepare covers all nslot jobs
-        } else {
+        } else if (nfloat > 0 || !did_i) {
             if (nfloat > 0) c->counters[MNW_C_TWO_PASS_BATCHES]++;
             rc = prepare_slot(c, sl, s, nslot, true);
             if (rc) return rc;
             rc = launch_encode_range(c, sl, s, 0, nfloat, MNW_FLOAT_GROUP);
         }
         if (rc) return rc;
-        rc = launch_encode_range(c, sl, s, nfloat, nslot, MNW_INT_GROUP);
-        if (rc) return rc;
+        if (!did_i) {
+            rc = launch_encode_range(c, sl, s, nfloat, nslot, MNW_INT_GROUP);
+            if (rc) return rc;
+        }
     }
     rc = release_slot(c, sl, s);
     if (rc) return rc;
@@ -1187,27 +1251,35 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, wait_stream(s));
     const int njobs = (int)c->pend_jobs.size();
-    if (c->pend_mode != 0 && c->pend_nfloat > 0 && sl->h_sync[0] != 0) {
-        // The fused launch gave up (its workgroups were not all co-resident, e.g. another kernel held
-        // part of the GPU): rerun the float jobs through the two-kernel path.  Still the GPU path.
+    const bool f_reg = c->pend_mode != 0 && c->pend_nfloat > 0, i_reg = c->pend_int_reg;
+    c->pend_int_reg = false;
+    if ((f_reg || i_reg) && sl->h_sync[0] != 0) {
+        // The persistent launch gave up (its workgroups were not all co-resident, e.g. another kernel held
+        // part of the GPU): rerun its jobs through the two-kernel path.  Still the GPU path.
         c->counters[MNW_C_SINGLE_READ_ABORTS]++;
         sl->shadow_tag = 0;                       // the abort word on the device is set: the next batch must prepare
-        for (int k = 0, g0 = 0; g0 < c->pend_nfloat; ) {   // group-relative tile numbering again
-            (void)k;
-            int g1 = g0; int64_t bytes = 0, tiles = 0;
-            while (g1 < c->pend_nfloat && (g1 == g0 || bytes + sl->h_jobs[g1].n * 4 <= c->group_bytes)) {
-                sl->h_jobs[g1].tile0 = tiles;
-                bytes += sl->h_jobs[g1].n * 4;
-                tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
-                ++g1;
+        for (int pass = 0; pass < 2; ++pass) {    // group-relative tile numbering again
+            if (!(pass == 0 ? f_reg : i_reg)) continue;
+            const int j0 = pass == 0 ? 0 : c->pend_nfloat, j1 = pass == 0 ? c->pend_nfloat : c->pend_nslot;
+            const int64_t esz = pass == 0 ? 4 : 8;
+            for (int g0 = j0; g0 < j1; ) {
+                int g1 = g0; int64_t bytes = 0, tiles = 0;
+                while (g1 < j1 && (g1 == g0 || bytes + sl->h_jobs[g1].n * esz <= c->group_bytes)) {
+                    sl->h_jobs[g1].tile0 = tiles;
+                    bytes += sl->h_jobs[g1].n * esz;
+                    tiles += (sl->h_jobs[g1].n + mnw::kTile - 1) / mnw::kTile;
+                    ++g1;
+                }
+                g0 = g1;
             }
-            g0 = g1;
         }
-        int rc = stage_xforms(c, sl, s, c->pend_nfloat);
+        int rc = f_reg ? stage_xforms(c, sl, s, c->pend_nfloat) : MNW_OK;
         if (rc) return rc;
-        rc = prepare_slot(c, sl, s, c->pend_nfloat, true);
+        rc = prepare_slot(c, sl, s, c->pend_nslot, true);
         if (rc) return rc;
-        rc = launch_encode_range(c, sl, s, 0, c->pend_nfloat, MNW_FLOAT_GROUP);
+        if (f_reg) rc = launch_encode_range(c, sl, s, 0, c->pend_nfloat, MNW_FLOAT_GROUP);
+        if (rc) return rc;
+        if (i_reg) rc = launch_encode_range(c, sl, s, c->pend_nfloat, c->pend_nslot, MNW_INT_GROUP);
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(s));
     }

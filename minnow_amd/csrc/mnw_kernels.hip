@@ -1614,6 +1614,273 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// single-read int64 encode (k_encode_reg_i64): intGroup.writeData (go/group.go:242-255) with the block read ONCE, the
+// same resident two-stage pipeline and tagged-record exchange as k_encode_reg_f32 (its header has the protocol and the
+// deadlock argument).  An item = 4,096 consecutive int64 = 32 KB = 16 values per lane; the parked item sits in LDS as raw
+// int64 in the 64-bit stage layout (32-element groups at a 68-dword stride), and lanes 0..127 pack one group of 32 each.
+// A record = the item's max and min as four self-validating words {high half, tag} {low half, tag} (max), (min); a block's
+// statistics are the 64-bit max / min over its records.  Widths above 32 bits (a block whose values span more than 2^32)
+// are packed in place in the LDS stage (pack_group64_inplace).  Blocks of at most min(G, 512) items (2^21 elements): flat
+// sweep only; anything larger, and explicit-mode jobs (raw bit arrays), stay on k_reduce_i64 + k_pack_i64.
+// ------------------------------------------------------------------------------------------------
+constexpr int kItemI = 4096;                        // int64 elements per item (32 KB, like a float item)
+constexpr int kBufI = (kItemI / kGroup) * kStride64;      // dwords of the parked item: 128 groups x 68 dwords = 34,816 B
+__device__ __forceinline__ int64_t items_of_i(int64_t n) { return (n + kItemI - 1) / kItemI; }
+
+struct DescI { int64_t imin; int bits; int status; int64_t nbytes; };
+
+// 33..64-bit widths: the lane re-bases and packs its group of 32 raw int64 IN PLACE.  After value i the stream has
+// (i + 1) b / 32 <= 2 (i + 1) complete words, which overwrite dwords of values <= i only, all of them read already.
+// Values at and beyond `nvalid` (past the block's end) pack as zero.
+__device__ __forceinline__ void pack_group64_inplace(uint32_t* __restrict__ grp, uint32_t b, uint64_t imin, uint64_t mask, int nvalid) {
+    uint32_t acc = 0, pos = 0;
+    const uint32_t bh = b - 32;                    // 1..32
+    uint32_t* out = grp;
+#pragma unroll 1
+    for (int i = 0; i < kGroup; ++i) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(grp + 2 * i);
+        const uint64_t v = i < nvalid ? (((((uint64_t)w.y << 32) | w.x) - imin) & mask) : 0ull;      // group.go:247, bit.go:104-107
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        acc |= lo << pos;
+        *out++ = acc;
+        acc = pos ? lo >> (32 - pos) : 0;
+        acc |= hi << pos;
+        pos += bh;
+        if (pos >= 32) {
+            *out++ = acc;
+            pos -= 32;
+            acc = pos ? hi >> (bh - pos) : 0;
+        }
+    }
+}
+
+// write-out after pack_group64_inplace: stream word w of the item sits at group w / b, dword w % b of that group
+template <int NT>
+__device__ __forceinline__ void store_tile_groups(const uint32_t* __restrict__ lds_in, uint32_t b, uint8_t* __restrict__ dst,
+                                                  int64_t tile_byte0, int64_t tile_bytes, int tid) {
+    const int full = (int)(tile_bytes >> 4);
+    for (int c = tid; c < full; c += NT) {
+        uint32_t g = (uint32_t)(4 * c) / b, off = (uint32_t)(4 * c) - g * b;
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            r[k] = lds_in[g * kStride64 + off];
+            if (++off == b) { off = 0; ++g; }
+        }
+        stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, u32x4{r[0], r[1], r[2], r[3]});
+    }
+    const int rem = (int)(tile_bytes & 15);
+    if (tid < rem) {
+        const uint32_t w = 4 * (uint32_t)full + ((uint32_t)tid >> 2);
+        const uint32_t g = w / b, off = w - g * b;
+        stg<uint8_t>(dst + tile_byte0 + 16 * (int64_t)full + tid, (uint8_t)(lds_in[g * kStride64 + off] >> (8 * (tid & 3))));
+    }
+}
+
+// wave 0.  Folds records (64-bit max / min from the four words of every record), returns false if one is missing.
+__device__ __forceinline__ bool fold_records_i64(const ItemRec* __restrict__ r0, int nitems, uint32_t gen, int64_t* mx, int64_t* mn) {
+    int64_t vmax = INT64_MIN, vmin = INT64_MAX;
+    uint32_t missing = 0;
+    for (int r = lane_id(); r < nitems; r += 64) {
+        uint64_t w[4];
+        load_rec_sc1(r0 + r, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) missing |= (uint32_t)(w[k] >> 32) != gen;
+        const int64_t a = (int64_t)(((uint64_t)(uint32_t)w[0] << 32) | (uint32_t)w[1]);
+        const int64_t b = (int64_t)(((uint64_t)(uint32_t)w[2] << 32) | (uint32_t)w[3]);
+        vmax = a > vmax ? a : vmax;
+        vmin = b < vmin ? b : vmin;
+    }
+    if (__any(missing)) return false;
+    *mx = wave_max_i64(vmax);
+    *mn = wave_min_i64(vmin);
+    return true;
+}
+
+__global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* __restrict__ jobs, int njobs, int64_t total_items,
+                                                                 const int* __restrict__ item_job, ItemRec* __restrict__ recs,
+                                                                 uint32_t gen, uint32_t* __restrict__ abort_flag,
+                                                                 uint32_t* __restrict__ abort_host, Meta* __restrict__ meta, int weighted,
+                                                                 int64_t drop_item) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kBufI];
+    __shared__ int64_t red[2][kThreadsR / 64];
+    __shared__ DescI desc_s;
+    __shared__ int abort_s;
+    constexpr int kV = kItemI / (2 * kThreadsR);       // 16-byte loads per lane per item (8)
+    constexpr int kW = kThreadsR / 64;
+    const int tid = threadIdx.x;
+    u32x4 e[kV];                                        // the current item: 16 int64 per lane, as (lo, hi) pairs
+    int cj = 0;
+    int64_t cbase = 0, cn = 0;
+    const int64_t* cx = nullptr;
+    auto locate = [&](int64_t t) {
+        cj = item_job[t];
+        cbase = (t - jobs[cj].tile0) * kItemI;
+        cn = jobs[cj].n;
+        cx = (const int64_t*)jobs[cj].src;
+    };
+    auto issue = [&]() {
+        if (cbase + kItemI <= cn) {
+            const int t = opaque_tid();
+#pragma unroll
+            for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(cx + cbase + k * (2 * kThreadsR) + 2 * t);
+        }
+    };
+    const int unit = weighted ? (int)gridDim.x / 4 : (int)gridDim.x;
+    int round = 0;
+    int64_t round_base = 0;
+    auto next_item = [&]() -> int64_t {
+        for (;;) {
+            round_base += (int64_t)(weighted ? kRoundQuarters[round] : 1) * unit;
+            round = round + 1 == kRounds ? 0 : round + 1;
+            if (round_base >= total_items) return total_items;
+            if ((int)blockIdx.x < (weighted ? kRoundQuarters[round] : 1) * unit) return round_base + blockIdx.x;
+        }
+    };
+    int64_t it = blockIdx.x;
+    bool have_cur = it < total_items;
+    if (have_cur) { locate(it); issue(); }
+    bool have_prev = false;
+    int pj = 0;
+    int64_t pbase = 0, pit = 0;
+    if (tid == 0) abort_s = 0;
+
+    while (have_cur || have_prev) {
+        const int sj = cj;
+        const int64_t sbase = cbase, sit = it;
+        const int64_t* const sx = cx + cbase;
+        const int64_t srem = cn - cbase;
+        const int64_t nit = have_cur ? next_item() : total_items;
+        const bool have_next = have_cur && nit < total_items;
+        if (have_next) locate(nit);
+
+        if (have_cur) {
+            // ---- statistics of item i: int64Min (group.go:350-357) and the max that ArrayBuffer.Bits needs (bit.go:151-159)
+            int64_t mn = INT64_MAX, mx = INT64_MIN;
+            if (srem >= kItemI) {
+#pragma unroll
+                for (int k = 0; k < kV; ++k) {
+                    const int64_t a = (int64_t)(((uint64_t)e[k].y << 32) | e[k].x), b = (int64_t)(((uint64_t)e[k].w << 32) | e[k].z);
+                    mn = a < mn ? a : mn; mx = a > mx ? a : mx;
+                    mn = b < mn ? b : mn; mx = b > mx ? b : mx;
+                }
+            } else {
+#pragma unroll 1
+                for (int i = tid; i < (int)srem; i += kThreadsR) {
+                    const int64_t a = ldg<int64_t>(sx + i);
+                    mn = a < mn ? a : mn; mx = a > mx ? a : mx;
+                }
+            }
+            mn = wave_min_i64(mn); mx = wave_max_i64(mx);
+            if (lane_id() == 0) { red[0][wave_id()] = mx; red[1][wave_id()] = mn; }
+        }
+        lds_barrier();
+        if (have_cur && tid < 4 && sit != drop_item) {           // (drop_item: test hook, see k_encode_reg_f32)
+            int64_t a = red[0][0], b = red[1][0];
+#pragma unroll
+            for (int w = 1; w < kW; ++w) { a = red[0][w] > a ? red[0][w] : a; b = red[1][w] < b ? red[1][w] : b; }
+            const uint64_t v64 = (uint64_t)(tid < 2 ? a : b);
+            const uint32_t half = (tid & 1) ? (uint32_t)v64 : (uint32_t)(v64 >> 32);
+            __hip_atomic_store(&recs[sit].g[tid], (uint64_t)half | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        if (have_prev) {
+            // ---- item i-1: the descriptor of its block (wave 0), then re-base and pack (lanes 0..127)
+            const DevJob pjb = jobs[pj];
+            if (wave_id() == 0) {
+                const int nitems = (int)items_of_i(pjb.n);
+                const ItemRec* r0 = recs + pjb.tile0;
+                uint32_t spins = 0;
+                const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                int64_t bmx = 0, bmn = 0;
+                bool ok = true;
+                while (!fold_records_i64(r0, nitems, gen, &bmx, &bmn)) {
+                    if (poll_abort(spins, t_start, abort_flag, abort_host)) { ok = false; break; }
+                }
+                if (lane_id() == 0) {
+                    DescI d = {bmn, 0, 0, 0};
+                    if (!ok) abort_s = 1;
+                    else {
+                        d.bits = precision_needed((uint64_t)bmx - (uint64_t)bmn);           // group.go:246-248, bit.go:151-159
+                        if (d.bits < 0) { d.status = -6; d.bits = 0; }
+                        else {
+                            d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, pjb.n);
+                            if (d.nbytes > pjb.cap) d.status = -5;
+                        }
+                        if (pit == pjb.tile0) { Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status}; meta[pj] = m; }
+                    }
+                    desc_s = d;
+                }
+            }
+            lds_barrier();
+            if (abort_s) break;                                    // (uniform: every wave reads the same word)
+            const DescI d = desc_s;
+            const int ok = __builtin_amdgcn_readfirstlane(d.status == 0 && d.bits != 0 && d.bits <= 32);
+            if (__builtin_amdgcn_readfirstlane(d.status == 0 && d.bits > 32)) {
+                // widths 33..64: in place, one group per lane of waves 0 and 1
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
+                if (tid < kItemI / kGroup) {
+                    const int64_t left = pjb.n - (pbase + (int64_t)kGroup * tid);
+                    pack_group64_inplace(lds + tid * kStride64, b, (uint64_t)d.imin, b == 64 ? ~0ull : ((1ull << b) - 1),
+                                         left >= kGroup ? kGroup : (left > 0 ? (int)left : 0));
+                }
+                lds_barrier();
+                const int64_t tile_byte0 = pbase / 8 * b;
+                int64_t tile_bytes = (int64_t)kItemI / 8 * b;
+                if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+                store_tile_groups<kThreadsR>(lds, b, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid());
+            }
+            uint32_t q[kGroup];
+            if (ok && tid < kItemI / kGroup) {
+                const uint64_t imin = (uint64_t)d.imin;
+                const uint32_t* grp = lds + tid * kStride64;
+#pragma unroll
+                for (int k = 0; k < kGroup / 2; ++k) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(grp + 4 * k);
+                    q[2 * k] = (uint32_t)((((uint64_t)r.y << 32) | r.x) - imin);      // group.go:247; below 2^32 by the choice of the width
+                    q[2 * k + 1] = (uint32_t)((((uint64_t)r.w << 32) | r.z) - imin);
+                }
+                if (pbase + kItemI > pjb.n) {
+                    const int64_t e0 = pbase + (int64_t)kGroup * tid;
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) if (e0 + i >= pjb.n) q[i] = 0;
+                }
+            }
+            lds_barrier();                                         // every packing lane holds its group: the stage can be overwritten
+            if (ok) {
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
+                if (tid < kItemI / kGroup) pack_group32_switch(q, b, lds + tid * b);
+                lds_barrier();
+                const int64_t tile_byte0 = pbase / 8 * b;
+                int64_t tile_bytes = (int64_t)kItemI / 8 * b;
+                if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
+                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid());
+            }
+            lds_barrier();
+        }
+        // ---- park item i, start item i+1
+        if (have_cur) {
+            if (srem >= kItemI) {
+#pragma unroll
+                for (int k = 0; k < kV; ++k)
+                    *reinterpret_cast<u32x4*>(lds + stage64_idx(2 * (k * kThreadsR + opaque_tid()))) = e[k];
+            } else {
+#pragma unroll 1
+                for (int i = tid; i < kItemI; i += kThreadsR) {
+                    const uint64_t v = i < (int)srem ? (uint64_t)ldg<int64_t>(sx + i) : 0ull;
+                    *reinterpret_cast<u32x2*>(lds + stage64_idx(i)) = u32x2{(uint32_t)v, (uint32_t)(v >> 32)};
+                }
+            }
+            if (have_next) issue();
+        }
+        have_prev = have_cur;
+        pj = sj; pbase = sbase; pit = sit;
+        it = nit;
+        have_cur = have_next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pack pass, int64 blocks (intGroup.writeData, and raw bit.BufferedArray in explicit mode).
 // The width is only known on the device, so the kernel carries both the 32-bit and the 64-bit path.
 // ------------------------------------------------------------------------------------------------
@@ -2070,6 +2337,17 @@ void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njob
     if (any_xform) { if (big) MNW_LAUNCH_REG(true, true); else MNW_LAUNCH_REG(true, false); }
     else { if (big) MNW_LAUNCH_REG(false, true); else MNW_LAUNCH_REG(false, false); }
 #undef MNW_LAUNCH_REG
+}
+void launch_encode_reg_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t drop_item) {
+    hipLaunchKernelGGL(k_encode_reg_i64, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
+                       abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, drop_item);
+}
+int64_t reg_item_elems_i64() { return kItemI; }
+int encode_reg_i64_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_i64, kThreadsR, 0) != hipSuccess) return 0;
+    return n;
 }
 size_t item_rec_bytes() { return sizeof(ItemRec); }
 int reg_max_items_per_block() { return kMaxSweep; }

@@ -547,6 +547,138 @@ def test_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
         assert c2.timing_get()["k_pack_f32"]["launches"] == 0
 
 
+def _int_blocks(rng):
+    """int64 blocks of every width class and ragged lengths, as one batch: (values, ...)."""
+    xs = []
+    for b, n in ((0, 5000), (1, 4096), (7, 4097), (21, 2**20), (21, 2**20 - 1), (32, 70001), (33, 4095), (37, 2**18 + 13),
+                 (48, 8192), (52, 12289), (63, 31), (64, 100000), (11, 2**21), (16, 1), (45, 2**21 - 4097), (20, 2**19)):
+        off = int(rng.integers(-10**12, 10**12))
+        if b == 64:
+            x = rng.integers(-(2**63), 2**63 - 2, size=n, dtype=np.int64)
+            x[:2] = (-(2**63), 2**63 - 2)
+        elif b == 0:
+            x = np.full(n, off, dtype=np.int64)
+        else:
+            x = off + rng.integers(0, 2**b, size=n, dtype=np.uint64).astype(np.int64)
+        xs.append(x)
+    return xs
+
+
+def test_int_single_read_batch_bit_exact(mnw, oracle, torch_mod):
+    """k_encode_reg_i64 (int64 blocks read once): a batch of blocks of every width class (0, <= 32, 33..64), ragged
+    lengths, up to the kernel's 2^21-element limit, alone and next to float blocks; the same batch with the option off
+    (k_reduce_i64 + k_pack_i64) gives the same bytes; the oracle (go/group.go:242-255, bit.go:79-159) checks both."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    xs = _int_blocks(rng)
+    want = [oracle.int_encode(x, literal=False) for x in xs]
+    fl = [np.mod(125 + 20 * rng.standard_normal(n), 250.0).astype(np.float32) for n in (2**20, 12345)]
+    fwant = [oracle.float_encode(x, 0.0, 250.0, 250000, True, literal=False) for x in fl]
+    with mnw.Context(0) as c2:
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+        fts = [torch.from_numpy(x).to(dev) for x in fl]
+        fouts = [torch.zeros(4 * x.size + 16, dtype=torch.uint8, device=dev) for x in fl]
+        ijobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.INT_GROUP) for t, o in zip(ts, outs)]
+        fjobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, 0.0, 250.0, 250000, 1)
+                 for t, o in zip(fts, fouts)]
+        torch.cuda.synchronize()
+        for mode, with_floats in (("reg", False), ("reg", True), ("two_pass", True), ("reg_float_two_pass", True), ("reg", True)):
+            c2.set_option("single_read_int", 0 if mode == "two_pass" else 1)
+            c2.set_option("single_read", 0 if mode == "reg_float_two_pass" else 1)
+            for o in outs + fouts:
+                o.zero_()
+            torch.cuda.synchronize()
+            c2.timing_enable(True); c2.timing_reset(); c2.counters_reset()
+            # int and float jobs interleaved in caller order
+            jobs = ijobs[:5] + (fjobs[:1] if with_floats else []) + ijobs[5:] + (fjobs[1:] if with_floats else [])
+            metas = c2.encode_blocks(jobs)
+            torch.cuda.synchronize()
+            kt = c2.timing_get()
+            ran = {k for k, v in kt.items() if v["launches"]}
+            cnt = c2.counters()
+            if mode == "two_pass":
+                assert "k_encode_reg_i64" not in ran and "k_pack_i64" in ran and cnt["int_single_read_batches"] == 0
+            else:
+                assert "k_encode_reg_i64" in ran and "k_pack_i64" not in ran and cnt["int_single_read_batches"] == 1, (mode, sorted(ran), cnt)
+            assert cnt["single_read_aborts"] == 0
+            if with_floats:
+                assert ("k_pack_f32" if mode == "reg_float_two_pass" else "k_encode_reg_f32") in ran
+            im = [m for m, j in zip(metas, jobs) if j.kind == mnw.INT_GROUP]
+            fm = [m for m, j in zip(metas, jobs) if j.kind == mnw.FLOAT_GROUP]
+            for x, m, o, (omin, obits, odata) in zip(xs, im, outs, want):
+                assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), (mode, x.size, m.min, m.bits, omin, obits)
+                assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), (mode, x.size, obits)
+                assert int(o[m.nbytes:].max()) == 0                                   # nothing written past the stream
+            for x, m, o, (omin, obits, odata) in zip(fl, fm, fouts, fwant):
+                assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+                assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        # blocks beyond the sweep's reach (more than 512 items of 4,096) keep the two launches
+        big = rng.integers(5, 2**27, size=2**21 + 4097, dtype=np.int64)
+        tb = torch.from_numpy(big).to(dev)
+        ob = torch.zeros(8 * big.size + 16, dtype=torch.uint8, device=dev)
+        c2.timing_reset(); c2.counters_reset()
+        m = c2.encode_blocks([mnw.EncJob(tb.data_ptr(), ob.data_ptr(), big.size, ob.numel(), mnw.INT_GROUP), ijobs[3]])
+        torch.cuda.synchronize()
+        assert c2.counters()["int_single_read_batches"] == 0 and c2.timing_get()["k_pack_i64"]["launches"] >= 1
+        omin, obits, odata = oracle.int_encode(big, literal=False)
+        assert (m[0].min, m[0].bits, m[0].nbytes) == (omin, obits, odata.size)
+        assert ob[: m[0].nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        # the domain error (go/bit.go:19-21 with max - min = 2^64 - 1) and a capacity error, per block, next to good blocks
+        bad = torch.tensor([-(2**63), 2**63 - 1, 5], dtype=torch.int64, device=dev)
+        obad = torch.zeros(64, dtype=torch.uint8, device=dev)
+        small = torch.zeros(16, dtype=torch.uint8, device=dev)
+        c2.counters_reset()
+        m = c2.encode_blocks([ijobs[1], mnw.EncJob(bad.data_ptr(), obad.data_ptr(), 3, 64, mnw.INT_GROUP),
+                              mnw.EncJob(ts[3].data_ptr(), small.data_ptr(), ts[3].numel(), 16, mnw.INT_GROUP), ijobs[2]], check=False)
+        torch.cuda.synchronize()
+        assert c2.counters()["int_single_read_batches"] == 1
+        assert [x.status for x in m] == [0, -6, -5, 0]
+        assert int(small.max()) == 0 and int(obad.max()) == 0
+        for k, mm in ((1, m[0]), (2, m[3])):
+            assert outs[k][: mm.nbytes].cpu().numpy().tobytes() == want[k][2].tobytes()
+
+
+def test_int_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
+    """The int kernel's give-up path (see test_single_read_abort_and_host_fallback): one item's record is never
+    published, the launch must end after its bounded wait and the host must rerun the int blocks -- and the float
+    blocks of the same batch -- through the reduce + pack launches.  Same bytes."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(78)
+    xs = [1000 + rng.integers(0, 2**b, size=n, dtype=np.int64) for b, n in ((21, 2**20), (37, 2**20), (8, 2**19 + 5))]
+    fx = np.mod(125 + 20 * rng.standard_normal(2**20), 250.0).astype(np.float32)
+    with mnw.Context(0) as c2:
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+        ft = torch.from_numpy(fx).to(dev)
+        fo = torch.zeros(4 * fx.size + 16, dtype=torch.uint8, device=dev)
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.INT_GROUP) for t, o in zip(ts, outs)]
+        jobs.append(mnw.EncJob(ft.data_ptr(), fo.data_ptr(), ft.numel(), fo.numel(), mnw.FLOAT_GROUP, 0.0, 250.0, 250000, 1))
+        torch.cuda.synchronize()
+        c2.set_option("reg_test_drop_item", 300)          # an item of the second int block; beyond the float block's 128 items
+        c2.timing_enable(True)
+        metas = c2.encode_blocks(jobs)
+        torch.cuda.synchronize()
+        kt = c2.timing_get()
+        assert kt["k_encode_reg_i64"]["launches"] == 1 and kt["k_pack_i64"]["launches"] >= 1 and kt["k_pack_f32"]["launches"] >= 1
+        assert c2.counters()["single_read_aborts"] == 1
+        for x, m, o in zip(xs, metas, outs):
+            omin, obits, odata = oracle.int_encode(x, literal=False)
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+            assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        omin, obits, odata = oracle.float_encode(fx, 0.0, 250.0, 250000, True, literal=False)
+        assert (metas[3].min, metas[3].bits, metas[3].nbytes) == (omin, obits, odata.size)
+        assert fo[: odata.size].cpu().numpy().tobytes() == odata.tobytes()
+        c2.set_option("reg_test_drop_item", -1)
+        c2.timing_reset()
+        metas2 = c2.encode_blocks(jobs)
+        torch.cuda.synchronize()
+        assert [(m.min, m.bits, m.nbytes) for m in metas2] == [(m.min, m.bits, m.nbytes) for m in metas]
+        assert c2.timing_get()["k_pack_i64"]["launches"] == 0 and c2.counters()["single_read_aborts"] == 1
+
+
 def _encode_and_compare(mnw, oracle, torch, c2, xs, low=0.0, high=250.0, pixels=250000, reps=1):
     dev = torch.device("cuda:0")
     ts = [torch.from_numpy(x).to(dev) for x in xs]

@@ -20,6 +20,7 @@ p.add_argument("--rows", type=int, default=10**8)
 p.add_argument("--block", type=int, default=2**20)
 p.add_argument("--reps", type=int, default=3)
 p.add_argument("--blocks-per-call", type=int, default=1, help="row blocks handed to the library per call")
+p.add_argument("--opt", action="append", default=[], help="library option name=value (mnw_set_option), repeatable")
 p.add_argument("--in-jobs", action="store_true", help="with --minh: pass the transforms as job flags (mnw_enc_job.xform) instead of separate calls")
 p.add_argument("--minh", action="store_true", help="include minh's processFloatGroup before the encode (the 18 log columns start as raw\n"
                "values, log10 + clamp on the GPU) and 10^x after the decode")
@@ -42,6 +43,8 @@ cols.append(("i", torch.randint(-1, 2**20, (R,), device=dev, dtype=torch.int64, 
 cols.append(("i", torch.full((R,), 7, device=dev, dtype=torch.int64), None))
 nblk = (R + B - 1) // B
 ctx = mnw.Context(0)
+for kv in a.opt:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 in_bytes = sum(t.numel() * t.element_size() for _, t, _ in cols)
 outs, decs, enc_batches, dec_protos = [], [], [], []
 # minh.Writer.Block's buffer (minh.buf): the processed copy of every FloatGroup column, encoded from there
