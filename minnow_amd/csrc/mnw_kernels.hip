@@ -1029,6 +1029,22 @@ __device__ __forceinline__ void load_rec_sc1(const ItemRec* p, uint64_t (&w)[4])
     w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32); w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
 }
 
+// The records of a block, one per lane, for use LATER in the trip: two 16-byte sc1 buffer loads the compiler can see (it
+// places the wait where the values are first used, and keeps its hands off the destination registers until then -- an
+// inline-asm load with a separate inline-asm wait does not give that: the compiler may copy a destination register in
+// between, before the data has arrived).  `base` must be wave-uniform.
+__device__ __forceinline__ void rec_prefetch(const ItemRec* base, int nrec, int idx, u32x4& a, u32x4& b) {
+    const uint64_t p = (uint64_t)base;
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    // (a lane at or beyond `nrec` is out of the buffer's range: zeros, no request.  Callers still branch around the call for
+    // such lanes -- a wave with no record then skips the instructions, 3 % of the headline launch -- and must leave the
+    // destinations UNASSIGNED on the other path: a value to merge with would make the compiler wait for the loads at the join.)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, __builtin_amdgcn_readfirstlane(nrec) * (int)sizeof(ItemRec), 0x00020000);
+    a = __builtin_amdgcn_raw_buffer_load_b128(r, idx * (int)sizeof(ItemRec), 0, 16);          // aux bit 4: sc1
+    b = __builtin_amdgcn_raw_buffer_load_b128(r, idx * (int)sizeof(ItemRec) + 16, 0, 16);
+}
+
 // wave 0 only, slow path: some record of the block was not there yet when the workgroup looked.  Polls
 // until all are present, then returns the descriptor word (0 on abort).
 __device__ __attribute__((noinline)) uint64_t sweep_block_f32(const DevJob* __restrict__ jobs, int j,
@@ -1328,11 +1344,11 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         int pitems = 0;
         uint64_t sw[4];
         u32x4 swa, swb;
+        int nrec = 0;
         if (have_prev) {
             pjb = jobs[pj];
             pitems = (int)items_of(pjb.n);
             const ItemRec* r0 = recs + pjb.tile0;
-            const uint64_t neutral = (uint64_t)gen << 32;
             // (a large block: the records of the parked item's GROUP, lanes 0..63 -- see group_duty_f32)
             int nload = pitems, first = 0;
             if (BIG && pitems > kMaxSweep) {
@@ -1343,15 +1359,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             // every workgroup of a block reads, and requests on one line are served one after the other (measured in one run,
             // tools/ab_libs.sh: 1e9 elements in 2^20-element blocks 1,174 -> 1,121 us, 2^22-element blocks 178 -> 170 us per
             // 1e8; one 16-byte load per lane -- lanes 2r, 2r+1 the halves of record r, one request per line -- was no better:
-            // 1,168 and 168 us, its parity-wise reduction costs what the requests save).  Issued here, waited for -- explicitly:
-            // the compiler does not see these loads -- where the fold below needs them.
-            swa = u32x4{0u, gen, 0u, gen}; swb = swa;
-            if (tid < nload) {
-                const MNW_GLOBAL ItemRec* rp = (const MNW_GLOBAL ItemRec*)(r0 + first + tid);
-                asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1"
-                             : "+v"(swa), "+v"(swb) : "v"(rp) : "memory");
-            }
-            (void)neutral;
+            // 1,168 and 168 us, its parity-wise reduction costs what the requests save).  Issued here, used by the fold below.
+            nrec = nload;
+            if (tid < nload) rec_prefetch(r0 + first, nload, tid, swa, swb);     // (waves without a record skip the instructions)
         }
 
         if (have_cur) {
@@ -1417,7 +1427,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
         }
         if (have_prev) {
             // fold what the record loads brought
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(swa), "+v"(swb) :: "memory");
+            if (tid >= nrec) { swa = u32x4{0u, gen, 0u, gen}; swb = swa; }        // no record for this lane: neutral words
             sw[0] = (uint64_t)swa.x | ((uint64_t)swa.y << 32); sw[1] = (uint64_t)swa.z | ((uint64_t)swa.w << 32);
             sw[2] = (uint64_t)swb.x | ((uint64_t)swb.y << 32); sw[3] = (uint64_t)swb.z | ((uint64_t)swb.w << 32);
             uint32_t v[4] = {0, 0, 0, 0};
@@ -1704,6 +1714,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
                                                                  int64_t drop_item) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufI];
     __shared__ int64_t red[2][kThreadsR / 64];
+    __shared__ int64_t swr[2][kThreadsR / 64];
+    __shared__ int swm[kThreadsR / 64];
     __shared__ DescI desc_s;
     __shared__ int abort_s;
     constexpr int kV = kItemI / (2 * kThreadsR);       // 16-byte loads per lane per item (8)
@@ -1754,8 +1766,19 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
         const bool have_next = have_cur && nit < total_items;
         if (have_next) locate(nit);
 
+        // ---- 1. the records of item i-1's block, one per lane, issued ahead of everything else of the trip (they were
+        // published a trip ago); folded after the statistics of item i
+        DevJob pjb;
+        int pitems = 0;
+        u32x4 swa, swb;
+        if (have_prev) {
+            pjb = jobs[pj];
+            pitems = (int)items_of_i(pjb.n);
+            if (tid < pitems) rec_prefetch(recs + pjb.tile0, pitems, tid, swa, swb);     // (waves without a record skip the instructions)
+        }
+
         if (have_cur) {
-            // ---- statistics of item i: int64Min (group.go:350-357) and the max that ArrayBuffer.Bits needs (bit.go:151-159)
+            // ---- 2. statistics of item i: int64Min (group.go:350-357) and the max that ArrayBuffer.Bits needs (bit.go:151-159)
             int64_t mn = INT64_MAX, mx = INT64_MIN;
             if (srem >= kItemI) {
 #pragma unroll
@@ -1774,6 +1797,25 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
             mn = wave_min_i64(mn); mx = wave_max_i64(mx);
             if (lane_id() == 0) { red[0][wave_id()] = mx; red[1][wave_id()] = mn; }
         }
+        if (have_prev) {
+            // fold what the record loads brought (blocks of more than 256 items: the second half follows)
+            const bool mine = tid < pitems;
+            uint32_t missing = mine && ((swa.y != gen) | (swa.w != gen) | (swb.y != gen) | (swb.w != gen));
+            int64_t vmax = mine ? (int64_t)(((uint64_t)swa.x << 32) | swa.z) : INT64_MIN;
+            int64_t vmin = mine ? (int64_t)(((uint64_t)swb.x << 32) | swb.z) : INT64_MAX;
+            if (pitems > kThreadsR && tid + kThreadsR < pitems) {
+                uint64_t w[4];
+                load_rec_sc1(recs + pjb.tile0 + kThreadsR + tid, w);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) missing |= (uint32_t)(w[k] >> 32) != gen;
+                const int64_t a = (int64_t)(((uint64_t)(uint32_t)w[0] << 32) | (uint32_t)w[1]);
+                const int64_t b = (int64_t)(((uint64_t)(uint32_t)w[2] << 32) | (uint32_t)w[3]);
+                vmax = a > vmax ? a : vmax; vmin = b < vmin ? b : vmin;
+            }
+            vmax = wave_max_i64(vmax); vmin = wave_min_i64(vmin);
+            const int miss = __any(missing);
+            if (lane_id() == 0) { swr[0][wave_id()] = vmax; swr[1][wave_id()] = vmin; swm[wave_id()] = miss; }
+        }
         lds_barrier();
         if (have_cur && tid < 4 && sit != drop_item) {           // (drop_item: test hook, see k_encode_reg_f32)
             int64_t a = red[0][0], b = red[1][0];
@@ -1785,17 +1827,20 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
         }
 
         if (have_prev) {
-            // ---- item i-1: the descriptor of its block (wave 0), then re-base and pack (lanes 0..127)
-            const DevJob pjb = jobs[pj];
+            // ---- 3. item i-1: the descriptor of its block (wave 0), then re-base and pack (lanes 0..127)
             if (wave_id() == 0) {
-                const int nitems = (int)items_of_i(pjb.n);
-                const ItemRec* r0 = recs + pjb.tile0;
-                uint32_t spins = 0;
-                const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-                int64_t bmx = 0, bmn = 0;
+                int64_t bmx = swr[0][0], bmn = swr[1][0];
+                int miss = swm[0];
+#pragma unroll
+                for (int w = 1; w < kW; ++w) { bmx = swr[0][w] > bmx ? swr[0][w] : bmx; bmn = swr[1][w] < bmn ? swr[1][w] : bmn; miss |= swm[w]; }
                 bool ok = true;
-                while (!fold_records_i64(r0, nitems, gen, &bmx, &bmn)) {
-                    if (poll_abort(spins, t_start, abort_flag, abort_host)) { ok = false; break; }
+                if (__builtin_expect(miss, 0)) {
+                    // some record was not there yet: poll until the block is complete (bounded: see poll_abort)
+                    uint32_t spins = 0;
+                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                    while (!fold_records_i64(recs + pjb.tile0, pitems, gen, &bmx, &bmn)) {
+                        if (poll_abort(spins, t_start, abort_flag, abort_host)) { ok = false; break; }
+                    }
                 }
                 if (lane_id() == 0) {
                     DescI d = {bmn, 0, 0, 0};
