@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNW_ABI_VERSION 4   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get; 4: MNW_K_COUNT 20 (k_encode_reg_i64) */
+#define MNW_ABI_VERSION 4   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get; 4: MNW_K_COUNT 21 (k_encode_reg_i64, k_encode_reg_vec3) */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MNW_OK            0
@@ -316,7 +316,8 @@ int mnw_unpack_u64_dev(mnw_ctx *ctx, mnw_stream_t stream, const uint8_t *in, int
 #define MNW_K_TEXT_PARSE  17  /* text ingest: fields and numbers (k_text_parse) */
 #define MNW_K_CUT         18  /* GenericCut: count + prefix, scatter */
 #define MNW_K_ENCODE_REG_I64 19 /* single-read int64 encode: the block is read once (k_encode_reg_i64) */
-#define MNW_K_COUNT       20
+#define MNW_K_ENCODE_REG_VEC3 20 /* minp vectors with the grid read once (k_encode_reg_vec3) */
+#define MNW_K_COUNT       21
 typedef struct mnw_kernel_time {
     double total_ms;     /* sum of event-timed durations */
     int64_t launches;
@@ -337,6 +338,7 @@ const char *mnw_kernel_name(int kernel_id);
 #define MNW_C_EXACT_BLOCKS        3  /* float blocks sent to the exact sequential path (out-of-domain data) */
 #define MNW_C_FUSED_BATCHES       4  /* float batches encoded by the opt-in fused launch k_encode_f32 */
 #define MNW_C_INT_SINGLE_READ_BATCHES 5 /* batches whose int64 blocks were encoded by k_encode_reg_i64 (aborts count in MNW_C_SINGLE_READ_ABORTS) */
+#define MNW_C_VEC3_SINGLE_READ_CALLS 6 /* mnw_vectors_encode calls that went through k_encode_reg_vec3 (aborts as above) */
 #define MNW_C_COUNT               8
 int mnw_counters_get(mnw_ctx *ctx, int64_t out[MNW_C_COUNT]);
 int mnw_counters_reset(mnw_ctx *ctx);
@@ -357,6 +359,9 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels
  *        when the geometry allows (n_sub and n_file multiples of four); 0 = always gather into the staging
  *        buffer first and run the block encoder on that.
+ * vec3_single_read: 1 = mnw_vectors_encode reads the grid once (k_encode_reg_vec3) when vec3_fused applies, 8 <= n_sub <= 128 and a
+ *        block has at most as many 2,048-particle vtiles as the launch has workgroups (and at most 1,024); 0 (default) =
+ *        k_reduce_vec3 + k_pack_vec3, which measured as fast on configs[3]'s geometry and need no co-resident grid.
  * vec3_tiles_per_wg: minp vector kernels: 2,048-particle tiles per workgroup (default 4; 0 = persistent grids).
  * host_threads: threads that copy between the caller's memory and the library's pinned buffers in the host-pointer entry
  *        points (default min(8, cores / 2)); set before the first such call.  stage_min_bytes: transfers below this size

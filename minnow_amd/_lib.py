@@ -10,9 +10,9 @@ STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
     -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
 }
-K_COUNT = 20
+K_COUNT = 21
 C_COUNT = 8
-COUNTER_NAMES = ("single_read_batches", "single_read_aborts", "two_pass_batches", "exact_blocks", "fused_batches", "int_single_read_batches")
+COUNTER_NAMES = ("single_read_batches", "single_read_aborts", "two_pass_batches", "exact_blocks", "fused_batches", "int_single_read_batches", "vec3_single_read_calls")
 
 
 class MnwError(RuntimeError):

@@ -47,6 +47,11 @@ void launch_bounds3(hipStream_t, int, const float*, int64_t, uint32_t*);
 void launch_reduce_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, uint64_t*);
 void launch_pack_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, const uint64_t*, Meta*);
 int64_t vec3_tiles(int64_t, int64_t);
+int64_t vec3_reg_recs(int64_t, int64_t);
+int64_t vec3_reg_max_tiles_per_block();
+bool vec3_reg_geometry_ok(int64_t, int64_t);
+int encode_reg_vec3_blocks_per_cu();
+void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t);
 void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float);
 constexpr int kMinhBatch = 64;
 struct MinhCol { const float* src; float* dst; int64_t n; float low, high, high_below; int32_t xform; };
@@ -253,6 +258,9 @@ struct mnw_ctx {
     int big_blocks = 1;          // ... including blocks of more than 512 items (two-level record sweep), up to twice the grid
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
+    int reg_vec3_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_vec3 per CU
+    int vec3_single_read = 0;    // minp vectors: 1 = the grid is read once (k_encode_reg_vec3) when the geometry allows.  Opt-in: measured
+                                 // no faster than k_reduce_vec3 + k_pack_vec3 on C4, and it needs its whole grid co-resident
     int reg_i64_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_i64 per CU
     int single_read_int = 1;     // int64 encode through k_encode_reg_i64 whenever the batch's int blocks are eligible
     bool pend_int_reg = false;   // the pending batch's int jobs went through k_encode_reg_i64
@@ -1003,6 +1011,7 @@ const char* mnw_kernel_name(int k) {
         case MNW_K_ENCODE_F32: return "k_encode_f32";
         case MNW_K_ENCODE_REG_F32: return "k_encode_reg_f32";
         case MNW_K_ENCODE_REG_I64: return "k_encode_reg_i64";
+        case MNW_K_ENCODE_REG_VEC3: return "k_encode_reg_vec3";
         case MNW_K_SUBCELL_GATHER: return "k_subcell_gather";
         case MNW_K_SUBCELL_SCATTER: return "k_subcell_scatter";
         case MNW_K_BOUNDS3: return "k_bounds3";
@@ -1066,6 +1075,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "fused")) { c->fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read_int")) { c->single_read_int = value != 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_single_read")) { c->vec3_single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_tiles_per_wg")) { c->vec3_tiles_per_wg = (int)value; return MNW_OK; }
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
@@ -1489,6 +1499,47 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
         rc = prepare_slot(c, sl, s, (int)(3 * s3), true);
         if (rc) return rc;
         const int64_t vt = mnw::vec3_tiles(n_file, sub_cells);
+        // ---- the grid read once (k_encode_reg_vec3): every block at most G vtiles for a resident grid of G workgroups ----
+        bool two_pass = true;
+        if (c->vec3_single_read) {
+            if (c->reg_vec3_blocks_per_cu == 0) {
+                const int occ = mnw::encode_reg_vec3_blocks_per_cu();
+                c->reg_vec3_blocks_per_cu = occ < 1 ? -1 : (occ > 3 ? 3 : occ);
+            }
+            int64_t grid = (int64_t)c->cus * c->reg_vec3_blocks_per_cu;
+            if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
+            if (vt < grid) grid = vt;
+            const int64_t T = vt / s3;
+            if (c->reg_vec3_blocks_per_cu >= 1 && T <= grid && T <= mnw::vec3_reg_max_tiles_per_block() && mnw::vec3_reg_geometry_ok(n_file, sub_cells)) {
+                const size_t need = (size_t)mnw::vec3_reg_recs(n_file, sub_cells) * mnw::item_rec_bytes();
+                if (need > c->cap_recs) {
+                    if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
+                    c->d_recs = nullptr; c->cap_recs = 0;
+                    const size_t want = need + need / 2 + 4096;
+                    HIPCHK(c, hipMalloc(&c->d_recs, want));
+                    HIPCHK(c, hipMemsetAsync(c->d_recs, 0, want, s));      // tags of a fresh buffer must not match any generation
+                    c->cap_recs = want;
+                }
+                c->reg_gen = (c->reg_gen + 1) & 0x7fffffffu;
+                if (c->reg_gen == 0) c->reg_gen = 1;
+                sl->h_sync[0] = 0;
+                { ScopedTimer t(c, s, MNW_K_ENCODE_REG_VEC3);
+                  mnw::launch_encode_reg_vec3(s, (int)grid, vec, n_file, sub_cells, sl->d_jobs, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
+                                              sl->d_meta, c->reg_drop_item); }
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, wait_stream(s));
+                c->counters[MNW_C_VEC3_SINGLE_READ_CALLS]++;
+                two_pass = false;
+                if (sl->h_sync[0] != 0) {
+                    // gave up (something else held part of the GPU): the two launches below redo the call
+                    c->counters[MNW_C_SINGLE_READ_ABORTS]++;
+                    rc = prepare_slot(c, sl, s, (int)(3 * s3), true);
+                    if (rc) return rc;
+                    two_pass = true;
+                }
+            }
+        }
+        if (two_pass) {
         int64_t grl = c->vec3_tiles_per_wg > 0 ? (vt + c->vec3_tiles_per_wg - 1) / c->vec3_tiles_per_wg : (int64_t)c->cus * 8;
         int64_t gpl = c->vec3_tiles_per_wg > 0 ? (vt + c->vec3_tiles_per_wg - 1) / c->vec3_tiles_per_wg : (int64_t)c->cus * 4;
         int gr = (int)(grl > vt ? vt : grl), gp = (int)(gpl > vt ? vt : gpl);
@@ -1496,6 +1547,7 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
         { ScopedTimer t(c, s, MNW_K_PACK_VEC3); mnw::launch_pack_vec3(s, gp, vec, n_file, sub_cells, sl->d_jobs, sl->d_stats, sl->d_meta); }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, wait_stream(s));
+        }
         bool exact = false;
         int first = MNW_OK;
         for (int64_t b = 0; b < 3 * s3; ++b) {

@@ -90,6 +90,17 @@ __device__ __forceinline__ T wave_reduce_dpp(T v, Op op) {
     const T r3 = __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
     return op(op(r0, r1), op(r2, r3));
 }
+// the same over each half of the wave: lo = lanes 0..31, hi = lanes 32..63 (both wave-uniform)
+__device__ __forceinline__ void half_wave_max_dpp(uint32_t v, uint32_t& lo, uint32_t& hi) {
+    auto dpp = [](uint32_t x, auto ctrl) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, decltype(ctrl)::value, 0xf, 0xf, true); };
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, dpp(v, std::integral_constant<int, 0xB1>{}));
+    v = mx(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+    v = mx(v, dpp(v, std::integral_constant<int, 0x141>{}));
+    v = mx(v, dpp(v, std::integral_constant<int, 0x140>{}));
+    lo = mx((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16));
+    hi = mx((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48));
+}
 __device__ __forceinline__ float wave_min_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fminf(a, b); }); }
 __device__ __forceinline__ float wave_max_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
 __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) { return wave_reduce_dpp(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }

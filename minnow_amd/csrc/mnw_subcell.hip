@@ -174,10 +174,16 @@ struct Vec3Args {
     uint32_t tiles_per_sc;    // vtiles per sub-cell
 };
 
-// the lane's two groups of four particles of vtile (sc, t): de-interleaved values, or `valid` false past the end
+// One group of four particles of a vtile as loaded: 48 contiguous bytes x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3.  The
+// vectors stay as the loads delivered them -- component k of particle c is word 3 c + k, a compile-time position -- and are
+// left UNASSIGNED past the end of the sub-cell (`valid` false; every user checks it): building de-interleaved vectors, or merging
+// with zeros, makes the compiler wait for the loads where they are issued, and nothing is in flight across the work that follows.
 struct Vec3Group {
-    sc_f32x4 x, y, z;
+    sc_f32x4 u, v, w;
     bool valid;
+    __device__ __forceinline__ float get(int k, int c) const { const int i = 3 * c + k; return i < 4 ? u[i] : i < 8 ? v[i - 4] : w[i - 8]; }
+    __device__ __forceinline__ void set(int k, int c, float f) { const int i = 3 * c + k; if (i < 4) u[i] = f; else if (i < 8) v[i - 4] = f; else w[i - 8] = f; }
+    __device__ __forceinline__ sc_f32x4 comp(int k) const { return sc_f32x4{get(k, 0), get(k, 1), get(k, 2), get(k, 3)}; }
 };
 __device__ __forceinline__ Vec3Group vec3_load(const Vec3Args& a, uint32_t sc, uint32_t j) {
     Vec3Group g;
@@ -185,10 +191,7 @@ __device__ __forceinline__ Vec3Group vec3_load(const Vec3Args& a, uint32_t sc, u
     if (g.valid) {
         const uint32_t i = particle_of(a.gm, sc * a.gm.n_sub3 + j);
         const MNW_GLOBAL_SC sc_f32x4* p = (const MNW_GLOBAL_SC sc_f32x4*)(a.vec + 3 * (int64_t)i);
-        const sc_f32x4 u = p[0], v = p[1], w = p[2];
-        g.x = sc_f32x4{u.x, u.w, v.z, w.y}; g.y = sc_f32x4{u.y, v.x, v.w, w.z}; g.z = sc_f32x4{u.z, v.y, w.x, w.w};
-    } else {
-        g.x = g.y = g.z = sc_f32x4{0, 0, 0, 0};
+        g.u = p[0]; g.v = p[1]; g.w = p[2];
     }
     return g;
 }
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, 4) void k_reduce_vec3(Vec3Args a, const DevJob
             if (!g.valid) return;
 #pragma unroll
             for (int c = 0; c < 4; c += 2) {
-                const float v0[3] = {g.x[c], g.y[c], g.z[c]}, v1[3] = {g.x[c + 1], g.y[c + 1], g.z[c + 1]};
+                const float v0[3] = {g.get(0, c), g.get(1, c), g.get(2, c)}, v1[3] = {g.get(0, c + 1), g.get(1, c + 1), g.get(2, c + 1)};
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     nonfinite |= __builtin_amdgcn_classf(v0[k], 0x207) | __builtin_amdgcn_classf(v1[k], 0x207);
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
                 u32x4 q[3];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float xv[3] = {g.x[c], g.y[c], g.z[c]};
+                    const float xv[3] = {g.get(0, c), g.get(1, c), g.get(2, c)};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         float rq = quant_mul(xv[k], low[k], rdx[k]);
@@ -405,6 +408,475 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
         }
         v0 = vend;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// minp.Writer.Vectors with the grid read ONCE (k_encode_reg_vec3): the resident pipeline and tagged-record exchange of
+// k_encode_reg_f32 (its header has the protocol) over vtiles, one stage deeper.  An item = one vtile = 2,048 particles of
+// one sub-cell, all three components (24 KB of the grid, 24 values per lane).
+// The three blocks of a sub-cell have 489 items each at C4's geometry and every workgroup needs all three descriptors every
+// trip, so the statistics are exchanged in TWO levels:
+//   item records   one per (component, vtile), published in the trip in which the vtile arrives;
+//   group records  the fold of kVGroup = 32 consecutive item records of a block, published by EVERY member of the group
+//                  (no leader: whichever member gets there first makes it available) in R copies -- copy d is read only by
+//                  the workgroups whose vtile is in group d (R = groups per block <= 32);
+// a trip reads 3 x (32 + R) records = 4.6 KB for C4, against 3 x 489 = 47 KB for a flat sweep of the item records.
+// A record that is read must have been published a whole trip before: under this kernel's load a memory round trip takes most
+// of a trip (the queues hold ~32 MB), so a read that has to be repeated costs a trip (measured: the group fold placed in
+// the same trip as the publication of its item records, 886 us for C4 against 497 us for the pipeline without any exchange).
+// Hence THREE items per workgroup: the NEW one (registers; its loads were issued a trip ago), the MIDDLE one (registers,
+// statistics published last trip) and the OLD one (LDS, three planes of pixel indices).  Per trip:
+//   all waves    statistics of NEW -> publish its three item records
+//   waves 0..2   (= components x, y, z; wave 3 has no part in this) one pair of record loads at the start of the trip, both
+//                kinds a trip old by then: lanes 0..31 the R group records of OLD's block, lanes 32..63 the item records of
+//                MIDDLE's group.  Upper half -> fold -> publish MIDDLE's group record (the group duty); lower half ->
+//                descriptor of OLD's block -> re-base, pack the component's plane in place, store
+//   all waves    MIDDLE -> quantize -> LDS; NEW becomes MIDDLE; issue the loads of the next vtile
+// No deadlock (unweighted rounds, blocks of at most G vtiles): the duty needs item records only and waits for nothing else; a
+// workgroup reaches the trip of a vtile once the blocks of its earlier vtiles are complete, which are strictly earlier blocks --
+// induction over the blocks in order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the
+// call through k_reduce_vec3 + k_pack_vec3.
+// HBM traffic = algorithmic: 12 B/particle read + the streams (+ the records, 13 % of that at C4).
+// ------------------------------------------------------------------------------------------------
+constexpr int kVGroup = 32;                 // vtiles per record group
+
+// all the records of a launch behind one buffer descriptor: lane-specific indices
+__device__ __forceinline__ void rec_prefetch_any(const ItemRec* base, uint32_t total_recs, int64_t idx, u32x4& a, u32x4& b) {
+    const uint64_t p = (uint64_t)base;
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)(total_recs * (uint32_t)sizeof(ItemRec)), 0x00020000);
+    const int off = (int)((uint32_t)idx * (uint32_t)sizeof(ItemRec));
+    a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+    b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 16);
+}
+
+struct Vec3RegArgs {
+    Vec3Args a;
+    ItemRec* recs;            // [3 s3][tiles_per_sc]
+    ItemRec* grecs;           // [3 s3][R reader groups][R]
+    uint32_t gen;
+    uint32_t R;               // groups per block
+    uint32_t* abort_flag;
+    uint32_t* abort_host;
+    int64_t drop_item;        // test hook: the records of that vtile are never published
+    uint32_t m_row, m_nsub;   // floor(2^32 / d) + 1 for d = n_sub / 4 and d = n_sub: x / d == umulhi(x, m) whenever x d < 2^32
+    uint32_t m_s, m_s2;       // the same for d = sub_cells and sub_cells^2
+};
+
+// vec3_load for this kernel: the sub-cell's origin is wave-uniform (scalar arithmetic), the lane's part of the index needs two
+// divisions by launch constants, done as multiply-high (exact here: n_sub <= 128, see the launch wrapper).  j4 = element / 4.
+__device__ __forceinline__ Vec3Group vec3_load_m(const Vec3RegArgs& ra, uint32_t base0, uint32_t j4) {
+    const SubcellGeom& gm = ra.a.gm;
+    Vec3Group g;
+    g.valid = 4 * j4 < gm.n_sub3;
+    if (g.valid) {
+        const uint32_t rowlen = gm.n_sub >> 2;
+        const uint32_t row = __umulhi(j4, ra.m_row), jx4 = j4 - row * rowlen;          // row = jy + n_sub jz
+        const uint32_t jz = __umulhi(row, ra.m_nsub), jy = row - jz * gm.n_sub;
+        const uint32_t i = base0 + 4 * jx4 + jy * gm.n_file + jz * gm.n_file2;
+        const MNW_GLOBAL_SC sc_f32x4* p = (const MNW_GLOBAL_SC sc_f32x4*)(ra.a.vec + 3 * (int64_t)i);
+        g.u = p[0]; g.v = p[1]; g.w = p[2];
+    }
+    return g;
+}
+
+// Twelve per-lane values -> their twelve wave-wide maxima, in lanes 0..3 (three each: lane q holds the values 6 (q & 1) + 3 (q >> 1) + {0, 1, 2}).
+// Two halving steps inside each quad (a lane keeps half of its values and takes the partner's half of those), then the three
+// survivors are folded over the quads of a row (row rotations keep the lane's position in its quad), then over the rows:
+// 42 vector instructions against 12 x 16 for one full-wave reduction per value.
+__device__ __forceinline__ void wave_max12(const float (&m)[12], float (&out)[3]) {
+    auto dpp = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    const int l = lane_id();
+    const bool b0 = l & 1, b1 = l & 2;
+    float r6[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float keep = b0 ? m[i + 6] : m[i], send = b0 ? m[i] : m[i + 6];
+        r6[i] = fmaxf(keep, dpp(send, std::integral_constant<int, 0xB1>{}));          // quad_perm [1,0,3,2]
+    }
+    float r3[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float keep = b1 ? r6[i + 3] : r6[i], send = b1 ? r6[i] : r6[i + 3];
+        r3[i] = fmaxf(keep, dpp(send, std::integral_constant<int, 0x4E>{}));          // quad_perm [2,3,0,1]
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float v = r3[i];
+        v = fmaxf(v, dpp(v, std::integral_constant<int, 0x124>{}));                   // row_ror:4
+        v = fmaxf(v, dpp(v, std::integral_constant<int, 0x128>{}));                   // row_ror:8
+        v = fmaxf(v, __shfl_xor(v, 16));
+        v = fmaxf(v, __shfl_xor(v, 32));
+        out[i] = v;
+    }
+}
+
+// what a block's descriptor needs of its job, the same for every sub-cell of a component (LDS copy, made once)
+struct Vec3JobPar {
+    float low, dxq;
+    int periodic, pad;
+    int64_t pixels, n, cap;
+};
+
+// Lanes 0..11 of one wave: the three descriptors of a sub-cell at once (lane = 4 component + word; desc_from_sweep_f32 across
+// three quads).  v = the lane's swept statistic, bad = a member of the lane's block was not finite.  The granule of component c
+// comes back in lanes 4c..4c+3; lane 4c writes the block's metadata if asked to.
+__device__ __forceinline__ uint64_t desc3_from_sweep_f32(const Vec3JobPar& jp, int64_t j, uint32_t v, bool bad, Meta* __restrict__ meta, bool write_meta) {
+    Desc d = {0, 0, 0, 0, 0};
+    const int l = lane_id(), r = l & 3, q0 = l & ~3;
+    const uint32_t key = (r & 1) ? ~v : v;
+    int64_t ql = 0;
+    const bool okl = quant_i64(funkey(key), jp.low, jp.dxq, &ql);
+    const bool has_lo = __shfl(v, q0 + 2) != 0, has_hi = __shfl(v, q0 + 3) != 0;
+    const uint32_t okmask = (uint32_t)(__ballot(okl) >> q0) & 15u;
+    const bool ok = (okmask & 3) == 3 && (!has_lo || (okmask & 4)) && (!has_hi || (okmask & 8));
+    const int64_t mx0 = __shfl(ql, q0), mn0 = __shfl(ql, q0 + 1), mxlo = __shfl(ql, q0 + 2), mnhi = __shfl(ql, q0 + 3);
+    uint64_t maxdelta = 0;
+    if (bad || !ok) {
+        d.status = (int)kNeedsExact;
+    } else if (jp.periodic == 1) {
+        if (mn0 < 0 || mx0 >= jp.pixels || jp.pixels > 0x7fffffffll) d.status = (int)kNeedsExact;
+        else {
+            const int64_t h = jp.pixels / 2;
+            if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+            else if (has_lo && has_hi && (mxlo + jp.pixels) - mnhi + 1 <= h) {
+                d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jp.pixels - mnhi);
+            } else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+        }
+    } else {
+        if (mn0 < -0x80000000ll || mx0 > 0x7fffffffll) d.status = (int)kNeedsExact;
+        else { d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+    }
+    if (d.status == 0) {
+        d.bits = precision_needed(maxdelta);
+        d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jp.n);
+        if (d.nbytes > jp.cap) d.status = -5;
+    }
+    if (write_meta && r == 0) {
+        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+        meta[j] = m;
+    }
+    return gran_encode(d);
+}
+
+#ifndef MNW_V3_DIAG
+#define MNW_V3_DIAG 0          // diagnostic builds only (wrong output): 1 = never wait for a group record, 2 = no group duty, 4 = duty without waiting
+#endif
+
+__global__ __launch_bounds__(256, 3) void k_encode_reg_vec3(Vec3RegArgs ra, const DevJob* __restrict__ jobs, Meta* __restrict__ meta) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[3 * kVPlane];
+    __shared__ float red[12][4];                         // NEW's statistics per wave, all as maxima (minima negated)
+    __shared__ int redbad[4];
+    __shared__ uint32_t swp[3][5];                       // OLD's block per component: the four swept statistics, flags
+    __shared__ uint64_t gran_s[3];
+    __shared__ Vec3JobPar jpar[3];
+    __shared__ int abort_s;
+    const Vec3Args& a = ra.a;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(wave_id()), l = lane_id();    // (uniform: the roles below are scalar branches)
+    const uint32_t T = a.tiles_per_sc, R = ra.R, s3 = a.s3, gen = ra.gen;
+    const uint32_t total = s3 * T;                       // (below 2^26: the host's record budget)
+    const uint32_t n_item_recs = 3u * s3 * T, n_group_recs = 3u * s3 * R * R;
+    // a round moves every workgroup on by G items = dsc sub-cells and dt vtiles
+    const uint32_t G = gridDim.x, dsc = G / T, dt = G - dsc * T;
+    if (tid < 3) {
+        const DevJob& jb = jobs[tid * s3];
+        Vec3JobPar p = {jb.low, jb.dxq, jb.periodic, 0, jb.pixels, jb.n, jb.cap};
+        jpar[tid] = p;
+    }
+    if (tid == 0) abort_s = 0;
+    // the quantization constants of the three components (the same for every sub-cell: mnw_vectors_encode fills them so)
+    float qlow[3], qdx[3], qxh[3];
+    double qrdx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * s3]; qlow[k] = jb.low; qdx[k] = jb.dxq; qrdx[k] = jb.rdx; qxh[k] = jb.xh; }
+
+    Vec3Group gn[2], gm[2];                             // the NEW item (in flight / just arrived) and the MIDDLE one
+    auto issue = [&](uint32_t sc, uint32_t t) {
+        // (scalar: the item is wave-uniform; sc < 2^15, so the divisions by sub_cells are multiply-highs as well)
+        const uint32_t S = a.gm.sub_cells;
+        const uint32_t sz = __umulhi(sc, ra.m_s2), q = sc - sz * S * S, sy = __umulhi(q, ra.m_s), sx = q - sy * S;
+        const uint32_t base0 = a.gm.n_sub * (sx + sy * a.gm.n_file + sz * a.gm.n_file2);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) gn[r] = vec3_load_m(ra, base0, t * (kVTile / 4) + tid + 256 * r);
+    };
+    // MIDDLE -> pixel indices, in place (its floats are not needed once its statistics are out): arithmetic only
+    auto quantize_mid = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            Vec3Group& g = gm[r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float xv[3] = {g.get(0, c), g.get(1, c), g.get(2, c)};
+                uint32_t qv[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float rq = quant_mul(xv[k], qlow[k], qrdx[k]);
+                    if (__builtin_expect(__builtin_amdgcn_classf(rq, 0x90), 0)) rq = __fdiv_rn(__fsub_rn(xv[k], qlow[k]), qdx[k]);
+                    qv[k] = g.valid ? (uint32_t)cvt_floor_i32(rq) : 0u;
+                }
+                g.set(0, c, __uint_as_float(qv[0])); g.set(1, c, __uint_as_float(qv[1])); g.set(2, c, __uint_as_float(qv[2]));
+            }
+        }
+    };
+    // The record loads of a trip (waves 0..2, component wv), issued at the end of the trip before, ahead of the loads of the next
+    // item, so that they are back when those are.  Lanes 0..31: the group records of (osc_, ot_)'s block, the copy row of that vtile's
+    // own group -- published during the trip that is ending; lanes 32..63: the item records of (msc_, mt_)'s group -- published at
+    // its start.  Both arrays sit behind one buffer descriptor (the group records follow the item records).
+    u32x4 ga, gb;
+    bool mine = false;
+    auto issue_records = [&](bool old_, uint32_t osc_, uint32_t ot_, bool mid_, uint32_t msc_, uint32_t mt_) {
+        mine = false;
+        if (wv < 3) {
+            // (32-bit, scalar but for the lane number, which is taken through opaque_tid: nothing lane-specific is kept across the trip)
+            const int lo = opaque_tid() & 63;
+            const uint32_t mfirst_ = mt_ / kVGroup * kVGroup;
+            const int mcnt_ = (int)(T - mfirst_ < (uint32_t)kVGroup ? T - mfirst_ : (uint32_t)kVGroup);
+            const uint32_t gbase = n_item_recs + ((uint32_t)(wv * s3 + osc_) * R + ot_ / kVGroup) * R;
+            const uint32_t ibase = (uint32_t)(wv * s3 + msc_) * T + mfirst_ - 32u;
+            const bool lower = lo < 32;
+            mine = lower ? (old_ && lo < (int)R) : (mid_ && lo - 32 < mcnt_ && !(MNW_V3_DIAG & 2));
+            if (mine) rec_prefetch_any(ra.recs, n_item_recs + n_group_recs, (int64_t)((lower ? gbase : ibase) + (uint32_t)lo), ga, gb);
+        }
+    };
+    // NEW, MIDDLE, OLD as (sub-cell, vtile)
+    uint32_t sc = blockIdx.x / T, t = blockIdx.x - sc * T, msc = 0, mt = 0, osc = 0, ot = 0;
+    bool have_new = blockIdx.x < total, have_mid = false, have_old = false;
+    if (have_new) issue(sc, t);
+    MNW_STAMP_DECL
+    MNW_STAMP_START
+    lds_barrier();
+
+    while (have_new || have_mid || have_old) {
+        uint32_t nsc = sc + dsc, nt = t + dt;
+        if (nt >= T) { nt -= T; ++nsc; }
+        const bool have_next = have_new && nsc < s3;
+
+        // ---- 1. (the record loads of this trip were issued at the end of the previous one, ahead of NEW's loads: see 5)
+        // NEW is complete from here on, on every path: the compiler waits once, here, not wherever NEW is touched next
+#pragma unroll
+        for (int r = 0; r < 2; ++r) asm volatile("" :: "v"(gn[r].u), "v"(gn[r].v), "v"(gn[r].w));
+        const uint32_t mgrp = mt / kVGroup, mfirst = mgrp * kVGroup;
+        const int mcnt = (int)(T - mfirst < (uint32_t)kVGroup ? T - mfirst : (uint32_t)kVGroup);
+
+        // ---- 2. statistics of NEW, per component (as k_reduce_vec3), all twelve as maxima
+        if (have_new) {
+            float m12[12];
+            bool nonfinite = false;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) m12[k] = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const Vec3Group& g = gn[r];
+                if (g.valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; c += 2) {
+                        const float v0[3] = {g.get(0, c), g.get(1, c), g.get(2, c)}, v1[3] = {g.get(0, c + 1), g.get(1, c + 1), g.get(2, c + 1)};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            nonfinite |= __builtin_amdgcn_classf(v0[k], 0x207) | __builtin_amdgcn_classf(v1[k], 0x207);
+                            m12[4 * k] = max3_raw(m12[4 * k], -v0[k], -v1[k]);                      // -min
+                            m12[4 * k + 1] = max3_raw(m12[4 * k + 1], v0[k], v1[k]);                 // max
+                            const bool l0 = v0[k] < qxh[k], l1 = v1[k] < qxh[k];
+                            m12[4 * k + 2] = max3_raw(m12[4 * k + 2], l0 ? v0[k] : -INFINITY, l1 ? v1[k] : -INFINITY);     // max below the split
+                            m12[4 * k + 3] = max3_raw(m12[4 * k + 3], l0 ? -INFINITY : -v0[k], l1 ? -INFINITY : -v1[k]);   // -min at / above it
+                        }
+                    }
+                }
+            }
+            float o3[3];
+            wave_max12(m12, o3);
+            if (l < 4) {
+                const int base = 6 * (l & 1) + 3 * (l >> 1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) red[base + i][wv] = o3[i];
+            }
+            const int bad = __any(nonfinite);
+            if (l == 0) redbad[wv] = bad;
+        }
+        MNW_STAMP(0)      // wait for NEW's loads (the records arrive before them), lane statistics, wave reductions
+        // waves 0..2: fold both halves (wave k: block k's group records, and component k's group duty)
+        uint32_t gv[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+        uint32_t gfl = 0, dfl = 0;                         // bit 0: a record is missing, bit 1: a member was not finite (lower / upper half)
+        if (wv < 3) {
+            uint32_t missing = 0, bad = 0;
+            uint32_t vl[4] = {0, 0, 0, 0};
+            if (mine) {
+                const uint32_t tg[4] = {ga.y, ga.w, gb.y, gb.w};
+                vl[0] = ga.x; vl[1] = ga.z; vl[2] = gb.x; vl[3] = gb.z;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { missing |= (tg[k] & ~kRecBad) != gen; bad |= tg[k] & kRecBad; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) half_wave_max_dpp(vl[k], gv[k], dv[k]);
+            const uint64_t mm = __ballot(missing != 0), bm = __ballot(bad != 0);
+            gfl = ((uint32_t)mm ? 1u : 0u) | ((uint32_t)bm ? 2u : 0u);
+            dfl = ((uint32_t)(mm >> 32) ? 1u : 0u) | ((uint32_t)(bm >> 32) ? 2u : 0u);
+            if (have_old) {
+                if (__builtin_expect((gfl & 1u) && !(MNW_V3_DIAG & 1), 0)) {
+                    // a group record was not there yet (its group more than a trip behind): poll the row
+                    uint32_t spins = 0;
+                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                    const ItemRec* row = ra.grecs + ((int64_t)(wv * s3 + osc) * R + ot / kVGroup) * R;
+                    for (;;) {
+                        uint64_t w[4] = {0, 0, 0, 0};
+                        uint32_t ms = 0, bd = 0;
+                        if (l < (int)R) {
+                            load_rec_sc1(row + l, w);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { const uint32_t tag = (uint32_t)(w[k] >> 32); ms |= (tag & ~kRecBad) != gen; bd |= tag & kRecBad; }
+                        }
+                        if (!__any(ms)) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) gv[k] = wave_max_dpp(l < (int)R ? (uint32_t)w[k] : 0u);
+                            gfl = __any(bd) ? 2u : 0u;
+                            break;
+                        }
+                        if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; break; }
+                    }
+                }
+                if (l < 5) swp[wv][l] = l == 0 ? gv[0] : l == 1 ? gv[1] : l == 2 ? gv[2] : l == 3 ? gv[3] : gfl;
+            }
+        }
+        lds_barrier();
+        // ---- 3. publish NEW's three records (lanes 0..11: component tid / 4, word tid % 4)
+        if (have_new && tid < 12 && sc * T + t != (uint32_t)ra.drop_item) {
+            const int k = tid >> 2, w4 = tid & 3;
+            // word 0: max, 1: min, 2: max below the split, 3: min at / above it (red rows 4k + {1, 0, 2, 3})
+            const int row = 4 * k + (w4 == 0 ? 1 : w4 == 1 ? 0 : w4);
+            float v = fmaxf(fmaxf(red[row][0], red[row][1]), fmaxf(red[row][2], red[row][3]));
+            const int bd = redbad[0] | redbad[1] | redbad[2] | redbad[3];
+            uint32_t val;
+            if (w4 == 0) val = bd ? 0 : fkey(v);
+            else if (w4 == 1) val = bd ? 0 : (uint32_t)~fkey(-v);
+            else if (w4 == 2) val = (bd || v == -INFINITY) ? 0 : fkey(v);
+            else val = (bd || v == -INFINITY) ? 0 : (uint32_t)~fkey(-v);
+            const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (bd ? kRecBad : 0u)) << 32);
+            __hip_atomic_store(&ra.recs[(int64_t)(k * s3 + sc) * T + t].g[w4], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        MNW_STAMP(1)      // record fold (waits for the record loads) + barrier + publish
+        uint32_t qq[kGroup];
+        if (wv == 3) {
+            // ---- 4a. wave 3: the three descriptors of OLD's sub-cell, lanes 0..11
+            if (have_old && l < 12) {
+                const int c = l >> 2;
+                const uint64_t g = desc3_from_sweep_f32(jpar[c], (int64_t)c * s3 + osc, swp[c][l & 3], (swp[c][4] & 2u) != 0, meta, ot == 0);
+                if ((l & 3) == 0) gran_s[c] = g;
+            }
+        } else {
+            if (have_mid) quantize_mid();                 // (wave 3 does its share after the descriptors, while the others pack)
+            if (have_mid && !(MNW_V3_DIAG & 2)) {
+                // ---- 4b. waves 0..2: the group duty of MIDDLE for this component: publish the fold of its group's item records
+                const int member = (int)(mt - mfirst);
+                if (__builtin_expect((dfl & 1u) && !(MNW_V3_DIAG & 4), 0)) {
+                    // an item record of the group was not there yet (a neighbour more than a trip behind): poll
+                    uint32_t spins = 0;
+                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                    const ItemRec* r0 = ra.recs + (int64_t)(wv * s3 + msc) * T + mfirst;
+                    for (;;) {
+                        uint64_t w[4] = {0, 0, 0, 0};
+                        uint32_t ms = 0, bd = 0;
+                        if (l < mcnt) {
+                            load_rec_sc1(r0 + l, w);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { const uint32_t tag = (uint32_t)(w[k] >> 32); ms |= (tag & ~kRecBad) != gen; bd |= tag & kRecBad; }
+                        }
+                        if (!__any(ms)) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) dv[k] = wave_max_dpp(l < mcnt ? (uint32_t)w[k] : 0u);
+                            dfl = __any(bd) ? 2u : 0u;
+                            break;
+                        }
+                        if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { dfl = 1u; if (l == 0) abort_s = 1; break; }
+                    }
+                }
+                if (!(dfl & 1u) || (MNW_V3_DIAG & 4))
+                    publish_group_rec(ra.grecs + (int64_t)(wv * s3 + msc) * R * R, (int)R, (int)mgrp, member, mcnt,
+                                      dv[0], dv[1], dv[2], dv[3], (dfl & 2u) != 0, gen);
+            }
+            if (have_old) {
+                // the lane's 32 pixel indices of OLD's plane, while wave 3 works out the descriptors
+                const uint32_t* plane = lds + wv * kVPlane;
+#pragma unroll
+                for (int k8 = 0; k8 < kGroup / 4; ++k8) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(plane + l * kStride32 + 4 * k8);
+                    qq[4 * k8] = rr.x; qq[4 * k8 + 1] = rr.y; qq[4 * k8 + 2] = rr.z; qq[4 * k8 + 3] = rr.w;
+                }
+            }
+        }
+        MNW_STAMP(2)      // group duty, LDS read | descriptors
+        lds_barrier();                                   // descriptors visible; every lane holds its group: the planes can be overwritten
+        if (abort_s) break;
+        if (wv == 3 && have_mid) quantize_mid();
+        if (wv < 3 && have_old) {
+            // ---- 4c. re-base, pack, store
+            const Vec3JobPar& jp = jpar[wv];
+            const Desc dw = gran_decode(gran_s[wv], jp.n);
+            if (__builtin_amdgcn_readfirstlane(dw.status == 0 && dw.bits != 0)) {
+                const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane(dw.bits);
+                const uint32_t iminw = (uint32_t)(int32_t)dw.imin;
+                const uint32_t wrapw = (jp.periodic == 1 && dw.pmin == dw.imin) ? (uint32_t)jp.pixels : 0u;
+                uint32_t* plane = lds + wv * kVPlane;
+                const int64_t e0 = (int64_t)ot * kVTile + kGroup * l;
+                if (wrapw == 0) {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) qq[i] -= iminw;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) { const uint32_t r2 = qq[i] - iminw; qq[i] = min(r2, r2 + wrapw); }
+                }
+                if (e0 + kGroup > jp.n) {
+#pragma unroll
+                    for (int i = 0; i < kGroup; ++i) if (e0 + i >= jp.n) qq[i] = 0;
+                }
+                pack_group32_switch(qq, bw, plane + l * bw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MNW_STAMP(3)      // re-base, pack
+                const int64_t byte0 = (int64_t)ot * (kVTile / 8) * bw;
+                int64_t nbytes_t = (int64_t)(kVTile / 8) * bw;
+                if (byte0 + nbytes_t > dw.nbytes) nbytes_t = dw.nbytes - byte0;
+                uint8_t* dst = (uint8_t*)jobs[(int64_t)wv * s3 + osc].dst;
+                const int full = (int)(nbytes_t >> 4);
+                for (int c = l; c < full; c += 64)
+                    stg<u32x4>(dst + byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(plane + 4 * c));
+                const int rem = (int)(nbytes_t & 15);
+                if (l < rem) {
+                    const uint32_t w = plane[4 * full + (l >> 2)];
+                    stg<uint8_t>(dst + byte0 + 16 * (int64_t)full + l, (uint8_t)(w >> (8 * (l & 3))));
+                }
+            }
+        }
+        lds_barrier();                                   // planes free
+        MNW_STAMP(4)      // stores issued + barrier
+        // ---- 5. next trip's record loads; MIDDLE's pixel indices -> LDS; NEW becomes MIDDLE; start the next item
+        issue_records(have_mid, msc, mt, have_new, sc, t);
+        if (have_mid) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t e = 4 * (tid + 256 * r);                // element of the vtile
+                const Vec3Group& g = gm[r];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<sc_f32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = g.comp(k);
+            }
+        }
+        if (have_new) {
+            // (the copy is pinned here, ahead of the loads: left to the compiler it becomes a copy at the loop's back edge, the
+            // loads then go to temporaries and are WAITED FOR there to be moved into NEW's registers)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                gm[r] = gn[r];
+                asm volatile("" : "+v"(gm[r].u), "+v"(gm[r].v), "+v"(gm[r].w));
+            }
+            if (have_next) issue(nsc, nt);
+        }
+        MNW_STAMP(5)      // quantize + park MIDDLE, next loads issued
+        have_old = have_mid; osc = msc; ot = mt;
+        have_mid = have_new; msc = sc; mt = t;
+        sc = nsc; t = nt;
+        have_new = have_next;
+    }
+    MNW_STAMP_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +1008,44 @@ void launch_pack_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file,
     a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
     a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
     hipLaunchKernelGGL(k_pack_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats, meta);
+}
+// single-read vectors encode.  recs: 3 s3 T item records, then 3 s3 R R group records (R = ceil(T / kVGroup)).
+int64_t vec3_reg_recs(int64_t n_file, int64_t sub_cells) {
+    const SubcellGeom g = make_geom(n_file, sub_cells);
+    const int64_t s3 = sub_cells * sub_cells * sub_cells, T = (g.n_sub3 + kVTile - 1) / kVTile, R = (T + kVGroup - 1) / kVGroup;
+    return 3 * s3 * (T + R * R);
+}
+int64_t vec3_reg_max_tiles_per_block() { return 32 * kVGroup; }           // R <= 32: one group record per lane of a half wave
+// geometries k_encode_reg_vec3 takes: its multiply-high divisions need 8 <= n_sub <= 128 and sub_cells <= 32, its record
+// offsets fewer than 2^26 records
+bool vec3_reg_geometry_ok(int64_t n_file, int64_t sub_cells) {
+    if (sub_cells < 1 || sub_cells > 32 || n_file % sub_cells) return false;
+    const int64_t n_sub = n_file / sub_cells;
+    if (n_sub < 8 || n_sub > 128 || n_sub % 4 || n_file % 4) return false;
+    return vec3_reg_recs(n_file, sub_cells) < (1ll << 26);
+}
+int encode_reg_vec3_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_vec3, 256, 0) != hipSuccess) return 0;
+    return n;
+}
+void launch_encode_reg_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, void* recs,
+                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item) {
+    Vec3RegArgs ra;
+    ra.a.vec = vec; ra.a.gm = make_geom(n_file, sub_cells);
+    ra.a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
+    ra.a.tiles_per_sc = (ra.a.gm.n_sub3 + kVTile - 1) / kVTile;
+    ra.R = (ra.a.tiles_per_sc + kVGroup - 1) / kVGroup;
+    ra.recs = (ItemRec*)recs;
+    ra.grecs = ra.recs + (size_t)3 * ra.a.s3 * ra.a.tiles_per_sc;
+    ra.gen = gen; ra.abort_flag = abort_flag; ra.abort_host = abort_host; ra.drop_item = drop_item;
+    // multiply-high division: exact for x d < 2^32; here x < n_sub^3 / 4 with d = n_sub / 4, and x < n_sub^2 with d = n_sub
+    // (the host only sends n_sub <= 128 here: vec3_reg_max_tiles_per_block)
+    ra.m_row = (uint32_t)((1ull << 32) / (ra.a.gm.n_sub / 4)) + 1u;
+    ra.m_nsub = (uint32_t)((1ull << 32) / ra.a.gm.n_sub) + 1u;
+    ra.m_s = sub_cells == 1 ? 0u : (uint32_t)((1ull << 32) / sub_cells) + 1u;              // (one sub-cell: every quotient is 0)
+    ra.m_s2 = sub_cells == 1 ? 0u : (uint32_t)((1ull << 32) / (sub_cells * sub_cells)) + 1u;
+    hipLaunchKernelGGL(k_encode_reg_vec3, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
 }
 int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
     const int64_t n_sub = n_file / sub_cells, n3 = n_sub * n_sub * n_sub;

@@ -192,11 +192,11 @@ def test_c4_shaped_file_cell(mnw, ctx2, torch_mod):
         assert torch.equal(first, packed)
 
 
-@pytest.mark.parametrize("fused", [1, 0])
-def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod, fused):
-    """n_sub and n_file multiples of four: mnw_vectors_encode reads the grid directly (k_reduce_vec3 + k_pack_vec3)
-    unless vec3_fused = 0; both must give the oracle's blocks.  Includes a partial last vtile (n_sub^3 = 13,824 =
-    6 * 2,048 + 1,536), a constant component (bits == 0) and a wrapped ring."""
+@pytest.mark.parametrize("fused,single", [(1, 1), (1, 0), (0, 0)])
+def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod, fused, single):
+    """n_sub and n_file multiples of four: mnw_vectors_encode reads the grid directly -- once (k_encode_reg_vec3), or twice
+    with vec3_single_read = 0 (k_reduce_vec3 + k_pack_vec3) -- unless vec3_fused = 0; all must give the oracle's blocks.
+    Includes a partial last vtile (n_sub^3 = 13,824 = 6 * 2,048 + 1,536), a constant component (bits == 0) and a wrapped ring."""
     from minnow_amd import minp
     torch = torch_mod
     dev = torch.device("cuda:0")
@@ -209,10 +209,13 @@ def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod
     pos[:, 2] = np.float32(17.25)                                                            # constant: every block is 0 bits
     with mnw.Context(0) as c:
         c.set_option("vec3_fused", fused)
+        c.set_option("vec3_single_read", single)
         c.timing_enable(True)
         _roundtrip(mnw, c, oracle, torch, dev, np.ascontiguousarray(pos), nf, sub_cells, 0.001, True, L)
         ran = {k for k, v in c.timing_get().items() if v["launches"]}
-        assert ("k_pack_vec3" in ran) == bool(fused) and ("k_subcell_gather" in ran) == (not fused)
+        assert ("k_pack_vec3" in ran) == bool(fused and not single) and ("k_subcell_gather" in ran) == (not fused)
+        assert ("k_encode_reg_vec3" in ran) == bool(fused and single)
+        assert c.counters()["vec3_single_read_calls"] == (1 if fused and single else 0) and c.counters()["single_read_aborts"] == 0
         assert ("k_unpack_vec3" in ran) == bool(fused) and ("k_subcell_scatter" in ran) == (not fused)
         # a NaN sends its block to the exact path: the fused kernels hand the whole call to the staging path
         bad = pos.copy(); bad[12345, 0] = np.nan
@@ -290,7 +293,19 @@ def test_c4_full_size_file_cell_vs_oracle(mnw, oracle, torch_mod):
         minp.vectors_decode(c, packed.data_ptr(), slot, metas, nf, S, low, high, pixels, True, L, out.data_ptr(), seed=5, first_block=2)
         torch.cuda.synchronize()
         ran = {k for k, v in c.timing_get().items() if v["launches"]}
-        assert {"k_reduce_vec3", "k_pack_vec3", "k_unpack_vec3"} <= ran, ran
+        assert {"k_reduce_vec3", "k_pack_vec3", "k_unpack_vec3"} <= ran and "k_encode_reg_vec3" not in ran, ran
+        # the single-read form (opt-in) gives the same file
+        first = packed.clone()
+        c.set_option("vec3_single_read", 1)
+        packed.zero_()
+        torch.cuda.synchronize()
+        metas2, *_ = minp.vectors_encode(c, pos.data_ptr(), nf, S, dx, True, L, packed.data_ptr(), slot)
+        torch.cuda.synchronize()
+        assert c.timing_get()["k_encode_reg_vec3"]["launches"] == 1 and c.timing_get()["k_pack_vec3"]["launches"] == 1
+        assert c.counters()["single_read_aborts"] == 0 and c.counters()["vec3_single_read_calls"] == 1
+        assert [(m.min, m.bits, m.nbytes, m.status) for m in metas2] == [(m.min, m.bits, m.nbytes, m.status) for m in metas]
+        assert torch.equal(first, packed)
+        del first
     vec = pos.cpu().numpy()
     blocks, omn, omx, opix = oracle.minp_vectors_encode(vec, nf, S, dx, True, L)
     assert np.array_equal(np.float32(low), omn) and np.array_equal(np.float32(high), omx) and list(pixels) == list(opix)
@@ -304,3 +319,62 @@ def test_c4_full_size_file_cell_vs_oracle(mnw, oracle, torch_mod):
     d = np.abs(got.astype(np.float64) - vec.astype(np.float64))
     d = np.minimum(d, L - d)
     assert d.max() <= dx * 1.01 + 1e-4
+
+
+@pytest.mark.parametrize("nf,sub_cells", [(96, 1), (120, 2), (160, 5)])
+def test_vectors_single_read_shapes_and_give_up(mnw, oracle, torch_mod, nf, sub_cells):
+    """k_encode_reg_vec3 on geometries with several record groups per block (n_sub^3 / 2,048 = 432, 105.5, 16 vtiles: 14, 4 and
+    1 groups of 32; a short last group; a partial last vtile) against the oracle, positions hugging the box seam in one
+    component; then the give-up path: a vtile's records are never published (test hook), the launch must end after its
+    bounded wait and the call must be redone by k_reduce_vec3 + k_pack_vec3 -- same blocks."""
+    from minnow_amd import minp
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + nf)
+    L, dx = 250.0, 0.001
+    g = make_vectors((0, 0, 0), L, nf)
+    pos = np.mod(g + 3.0 * rng.standard_normal(g.shape), L).astype(np.float32)
+    pos[:, 1] = np.mod(0.5 + 0.4 * rng.standard_normal(nf ** 3), L).astype(np.float32)
+    pos[pos >= np.float32(L)] = 0.0
+    pos = np.ascontiguousarray(pos)
+    n_sub = nf // sub_cells
+    nb = 3 * sub_cells ** 3
+    slot = (4 * n_sub ** 3 + 15) // 16 * 16
+    blocks, omn, omx, opix = oracle.minp_vectors_encode(pos, nf, sub_cells, dx, True, L)
+    t = torch.from_numpy(pos).to(dev)
+    packed = torch.zeros(nb * slot, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def check(metas):
+        host = packed.cpu().numpy()
+        for b, (m, (omin, obits, odata)) in enumerate(zip(metas, blocks)):
+            assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), b
+            assert host[b * slot: b * slot + m.nbytes].tobytes() == odata.tobytes(), b
+            assert not host[b * slot + m.nbytes: (b + 1) * slot].any()
+
+    with mnw.Context(0) as c:
+        c.set_option("vec3_single_read", 1)
+        c.timing_enable(True)
+        for rep in range(3):                      # (generations: the records of an earlier call must not satisfy a later one)
+            packed.zero_()
+            torch.cuda.synchronize()
+            metas, low, high, pixels = minp.vectors_encode(c, t.data_ptr(), nf, sub_cells, dx, True, L, packed.data_ptr(), slot)
+            torch.cuda.synchronize()
+            check(metas)
+        kt = c.timing_get()
+        assert kt["k_encode_reg_vec3"]["launches"] == 3 and kt["k_pack_vec3"]["launches"] == 0
+        assert c.counters()["vec3_single_read_calls"] == 3 and c.counters()["single_read_aborts"] == 0
+        c.set_option("reg_test_drop_item", (n_sub ** 3 + 2047) // 2048 // 2)        # a vtile in the middle of the first sub-cell
+        packed.zero_()
+        torch.cuda.synchronize()
+        metas, *_ = minp.vectors_encode(c, t.data_ptr(), nf, sub_cells, dx, True, L, packed.data_ptr(), slot)
+        torch.cuda.synchronize()
+        check(metas)
+        assert c.counters()["single_read_aborts"] == 1 and c.timing_get()["k_pack_vec3"]["launches"] == 1
+        c.set_option("reg_test_drop_item", -1)
+        packed.zero_()
+        torch.cuda.synchronize()
+        metas, *_ = minp.vectors_encode(c, t.data_ptr(), nf, sub_cells, dx, True, L, packed.data_ptr(), slot)
+        torch.cuda.synchronize()
+        check(metas)
+        assert c.counters()["single_read_aborts"] == 1 and c.timing_get()["k_encode_reg_vec3"]["launches"] == 5
