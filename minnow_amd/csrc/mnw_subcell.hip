@@ -172,7 +172,24 @@ struct Vec3Args {
     SubcellGeom gm;
     uint32_t s3;              // sub_cells^3
     uint32_t tiles_per_sc;    // vtiles per sub-cell
+    // Division by a launch constant d as a multiply-high: m = floor(2^32 / d) + 1 gives x / d == umulhi(x, m) whenever x d < 2^32.
+    // m_row: d = n_sub / 4 (x < n_sub^3 / 4), m_nsub: d = n_sub (x < n_sub^2); both 0 if n_sub >= 512 (then: ordinary division).
+    uint32_t m_row, m_nsub;
 };
+
+// first particle of the group of four that starts at element j (a multiple of 4) of sub-cell sc -- particle_of for the vtile kernels:
+// the sub-cell's origin is wave-uniform (scalar arithmetic), the lane's part costs two multiply-highs instead of two divisions
+__device__ __forceinline__ uint32_t vec3_particle(const Vec3Args& a, uint32_t sc, uint32_t j) {
+    const SubcellGeom& gm = a.gm;
+    if (a.m_row == 0) return particle_of(gm, sc * gm.n_sub3 + j);
+    const uint32_t s2 = gm.sub_cells * gm.sub_cells;
+    const uint32_t sz = sc / s2, q = sc - sz * s2, sy = q / gm.sub_cells, sx = q - sy * gm.sub_cells;
+    const uint32_t base0 = gm.n_sub * (sx + sy * gm.n_file + sz * gm.n_file2);
+    const uint32_t j4 = j >> 2, rowlen = gm.n_sub >> 2;
+    const uint32_t row = __umulhi(j4, a.m_row), jx4 = j4 - row * rowlen;          // row = jy + n_sub jz
+    const uint32_t jz = __umulhi(row, a.m_nsub), jy = row - jz * gm.n_sub;
+    return base0 + 4 * jx4 + jy * gm.n_file + jz * gm.n_file2;
+}
 
 // One group of four particles of a vtile as loaded: 48 contiguous bytes x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3.  The
 // vectors stay as the loads delivered them -- component k of particle c is word 3 c + k, a compile-time position -- and are
@@ -189,7 +206,7 @@ __device__ __forceinline__ Vec3Group vec3_load(const Vec3Args& a, uint32_t sc, u
     Vec3Group g;
     g.valid = j < a.gm.n_sub3;
     if (g.valid) {
-        const uint32_t i = particle_of(a.gm, sc * a.gm.n_sub3 + j);
+        const uint32_t i = vec3_particle(a, sc, j);
         const MNW_GLOBAL_SC sc_f32x4* p = (const MNW_GLOBAL_SC sc_f32x4*)(a.vec + 3 * (int64_t)i);
         g.u = p[0]; g.v = p[1]; g.w = p[2];
     }
@@ -953,7 +970,7 @@ __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restri
                             o[k][c] = wrap_once(x, L, periodic);
                         }
                     }
-                    const uint32_t i = particle_of(a.gm, sc * a.gm.n_sub3 + j);
+                    const uint32_t i = vec3_particle(a, sc, j);
                     MNW_GLOBAL_SC sc_f32x4* p = (MNW_GLOBAL_SC sc_f32x4*)(vec_out + 3 * (int64_t)i);
                     const sc_f32x4 q0 = {o[0].x, o[1].x, o[2].x, o[0].y}, q1 = {o[1].y, o[2].y, o[0].z, o[1].z},
                                    q2 = {o[2].z, o[0].w, o[1].w, o[2].w};
@@ -994,19 +1011,23 @@ void launch_bounds3(hipStream_t s, int cus, const float* vec, int64_t n, uint32_
     hipLaunchKernelGGL(k_bounds3, dim3(subcell_grid(n / 4 + 1, cus)), dim3(256), 0, s, vec, n, keys);
 }
 
-void launch_reduce_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, uint64_t* stats) {
+static Vec3Args make_vec3_args(const float* vec, int64_t n_file, int64_t sub_cells) {
     Vec3Args a;
     a.vec = vec; a.gm = make_geom(n_file, sub_cells);
     a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
     a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    const bool magic = a.gm.n_sub % 4 == 0 && a.gm.n_sub >= 8 && a.gm.n_sub < 512;      // x d < 2^32 for both divisions (and d >= 2)
+    a.m_row = magic ? (uint32_t)((1ull << 32) / (a.gm.n_sub / 4)) + 1u : 0u;
+    a.m_nsub = magic ? (uint32_t)((1ull << 32) / a.gm.n_sub) + 1u : 0u;
+    return a;
+}
+void launch_reduce_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, uint64_t* stats) {
+    const Vec3Args a = make_vec3_args(vec, n_file, sub_cells);
     hipLaunchKernelGGL(k_reduce_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats);
 }
 void launch_pack_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, const uint64_t* stats,
                       Meta* meta) {
-    Vec3Args a;
-    a.vec = vec; a.gm = make_geom(n_file, sub_cells);
-    a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
-    a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    const Vec3Args a = make_vec3_args(vec, n_file, sub_cells);
     hipLaunchKernelGGL(k_pack_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats, meta);
 }
 // single-read vectors encode.  recs: 3 s3 T item records, then 3 s3 R R group records (R = ceil(T / kVGroup)).
@@ -1032,9 +1053,7 @@ int encode_reg_vec3_blocks_per_cu() {
 void launch_encode_reg_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, void* recs,
                             uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item) {
     Vec3RegArgs ra;
-    ra.a.vec = vec; ra.a.gm = make_geom(n_file, sub_cells);
-    ra.a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
-    ra.a.tiles_per_sc = (ra.a.gm.n_sub3 + kVTile - 1) / kVTile;
+    ra.a = make_vec3_args(vec, n_file, sub_cells);
     ra.R = (ra.a.tiles_per_sc + kVGroup - 1) / kVGroup;
     ra.recs = (ItemRec*)recs;
     ra.grecs = ra.recs + (size_t)3 * ra.a.s3 * ra.a.tiles_per_sc;
@@ -1052,9 +1071,6 @@ int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
     return sub_cells * sub_cells * sub_cells * ((n3 + kVTile - 1) / kVTile);
 }
 void launch_unpack_vec3(hipStream_t s, int grid, float* vec_out, int64_t n_file, int64_t sub_cells, const DevJob* jobs, int periodic, float L) {
-    Vec3Args a;
-    a.vec = vec_out; a.gm = make_geom(n_file, sub_cells);
-    a.s3 = (uint32_t)(sub_cells * sub_cells * sub_cells);
-    a.tiles_per_sc = (a.gm.n_sub3 + kVTile - 1) / kVTile;
+    const Vec3Args a = make_vec3_args(vec_out, n_file, sub_cells);
     hipLaunchKernelGGL(k_unpack_vec3, dim3(grid), dim3(256), 0, s, a, vec_out, jobs, periodic, L);
 }
