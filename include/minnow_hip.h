@@ -362,6 +362,8 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * vec3_single_read: 1 = mnw_vectors_encode reads the grid once (k_encode_reg_vec3) when vec3_fused applies, 8 <= n_sub <= 128 and a
  *        block has at most as many 2,048-particle vtiles as the launch has workgroups (and at most 1,024); 0 (default) =
  *        k_reduce_vec3 + k_pack_vec3, which measured as fast on configs[3]'s geometry and need no co-resident grid.
+ * unlog_fused: 1 (default) = minh's reader transform 10^x (mnw_dec_job.xform & MNW_XF_LOG10) is applied inside the unpack kernel;
+ *        0 = by a pass over the decoded column afterwards (k_minh_unlog).  Same floats either way.
  * vec3_tiles_per_wg: minp vector kernels: 2,048-particle tiles per workgroup (default 4; 0 = persistent grids).
  * host_threads: threads that copy between the caller's memory and the library's pinned buffers in the host-pointer entry
  *        points (default min(8, cores / 2)); set before the first such call.  stage_min_bytes: transfers below this size

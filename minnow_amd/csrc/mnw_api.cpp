@@ -39,7 +39,7 @@ int reg_group_items();
 int encode_reg_f32_xf_blocks_per_cu();
 int64_t reg_item_elems();
 int encode_reg_f32_blocks_per_cu();
-void launch_unpack_f32(hipStream_t, int, bool, const DevJob*, int, int64_t);
+void launch_unpack_f32(hipStream_t, int, bool, bool, const DevJob*, int, int64_t);
 void launch_unpack_i64(hipStream_t, int, const DevJob*, int, int64_t);
 void launch_subcell_gather(hipStream_t, int, const float*, float*, int64_t, int64_t);
 void launch_subcell_scatter(hipStream_t, int, const float*, float*, int64_t, int64_t, int, float);
@@ -259,6 +259,7 @@ struct mnw_ctx {
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int reg_vec3_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_vec3 per CU
+    int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
     int vec3_single_read = 0;    // minp vectors: 1 = the grid is read once (k_encode_reg_vec3) when the geometry allows.  Opt-in: measured
                                  // no faster than k_reduce_vec3 + k_pack_vec3 on C4, and it needs its whole grid co-resident
     int reg_i64_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_i64 per CU
@@ -1076,6 +1077,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_read")) { c->single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "single_read_int")) { c->single_read_int = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_single_read")) { c->vec3_single_read = value != 0; return MNW_OK; }
+    if (!strcmp(name, "unlog_fused")) { c->unlog_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_tiles_per_wg")) { c->vec3_tiles_per_wg = (int)value; return MNW_OK; }
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
@@ -1337,6 +1339,7 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
     if (rc) return rc;
     // three launch classes: float 32-bit path, float 64-bit path, int64
     int cls_begin[4] = {0, 0, 0, 0};
+    bool cls_xf[3] = {false, false, false};
     int nslot = 0;
     for (int cls = 0; cls < 3; ++cls) {
         cls_begin[cls] = nslot;
@@ -1358,7 +1361,11 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
             d.min = j.min; d.bits = (int32_t)j.bits; d.seed = j.seed; d.block = j.block;
             d.low = j.low; d.high = j.high; d.kind = j.kind; d.periodic = j.periodic;
             d.mode = mnw::kModeExplicit;
-            if (j.kind == MNW_FLOAT_GROUP) d.dxq = quant_dx(j.low, j.high, j.pixels);   // group.go:305-306
+            if (j.kind == MNW_FLOAT_GROUP) {
+                d.dxq = quant_dx(j.low, j.high, j.pixels);   // group.go:305-306
+                d.xform = c->unlog_fused ? (j.xform & MNW_XF_LOG10) : 0;   // minh's 10^x inside the unpack kernel
+                cls_xf[cls] |= d.xform != 0;
+            }
             d.tile0 = tiles;
             tiles += (j.n + mnw::kTileD - 1) / mnw::kTileD;
         }
@@ -1376,12 +1383,13 @@ int mnw_decode_blocks(mnw_ctx* c, mnw_stream_t stream, const mnw_dec_job* jobs, 
         if (j1 == j0) continue;
         int64_t tiles = sl->h_jobs[j1 - 1].tile0 + (sl->h_jobs[j1 - 1].n + mnw::kTileD - 1) / mnw::kTileD;
         const int grid = decode_grid_for(c, tiles);
-        if (cls < 2) { ScopedTimer t(c, s, MNW_K_UNPACK_F32); mnw::launch_unpack_f32(s, grid, cls == 0, sl->d_jobs + j0, j1 - j0, tiles); }
+        if (cls < 2) { ScopedTimer t(c, s, MNW_K_UNPACK_F32); mnw::launch_unpack_f32(s, grid, cls == 0, cls_xf[cls], sl->d_jobs + j0, j1 - j0, tiles); }
         else { ScopedTimer t(c, s, MNW_K_UNPACK_I64); mnw::launch_unpack_i64(s, grid, sl->d_jobs + j0, j1 - j0, tiles); }
     }
     HIPCHK(c, hipGetLastError());
-    // minh's logarithmic columns: 10^x on the decoded values (go/minh/minh.go:315-319), a pass over the output
-    {
+    // minh's logarithmic columns: 10^x on the decoded values (go/minh/minh.go:315-319): inside the unpack kernel (above), or -- option
+    // unlog_fused = 0 -- as a pass over the output
+    if (!c->unlog_fused) {
         mnw::MinhArgs a;
         memset(&a, 0, sizeof a);
         int m = 0;

@@ -2120,12 +2120,19 @@ __device__ __forceinline__ uint64_t extract64(const uint64_t* __restrict__ l64, 
 // floatGroup.readData, group.go:299-310.  NARROW: bits <= 32 and min, min+2^bits, pixels fit int32.
 // The next tile's stream words are loaded into registers before the current tile is extracted, and
 // the LDS word buffer is double buffered: one barrier per tile, loads in flight across it.
-template <bool NARROW>
+// XF: the launch has jobs whose values go through minh's reader transform, float32(math.Pow(10, float64(x)))
+// (go/minh/minh.go:315-319; DevJob.xform & kXfLog10), applied to the decoded value before it is stored -- the column is
+// written once, not written, read back and written again by a pass of its own.  An instantiation of its own (2.5 KB of
+// tables in LDS, float64 arithmetic): the plain kernel is not touched.
+template <bool NARROW, bool XF>
 __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restrict__ jobs, int njobs,
                                                          int64_t total_tiles) {
     constexpr int kLW = kTileD / 64 * (NARROW ? 32 : 64) + 2;          // words per LDS buffer
     constexpr int kNW = (kLW + kThreads - 1) / kThreads;              // words per thread
     __shared__ __attribute__((aligned(16))) uint64_t lw2[2][kLW];
+    __shared__ typename std::conditional<XF, FastTables, double>::type ftab_s;
+    FastTables* const ftab_p = XF ? reinterpret_cast<FastTables*>(&ftab_s) : nullptr;
+    if (XF) fast_tables_load(ftab_p);
     const int tid = threadIdx.x;
     int64_t t0 = total_tiles * blockIdx.x / gridDim.x;
     const int64_t t1 = total_tiles * (blockIdx.x + 1) / gridDim.x;
@@ -2141,6 +2148,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
         const uint32_t b = (uint32_t)jb.bits;
         const float low = jb.low, dx = jb.dxq;
         const bool per = jb.periodic == 1;
+        const bool unlog = XF && (jb.xform & kXfLog10);
         const uint64_t mask64 = b == 0 ? 0 : (b == 64 ? ~0ull : ((1ull << b) - 1));
         const StreamView sv = stream_view(jb, b);
         uint64_t w[kNW];
@@ -2189,6 +2197,10 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
 #endif
                     // group.go:308: dx*float32(float64(q) + u) + low, float32 multiply then add
                     r[c] = __fadd_rn(__fmul_rn(dx, (float)__dadd_rn(qd, u)), low);
+                }
+                if (unlog) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = go_pow10_f32(r[c], ftab_p);
                 }
                 if (base + i0 + 3 < jb.n) {
                     stg<f32x4>(out + base + i0, r);
@@ -2428,9 +2440,14 @@ int encode_f32_blocks_per_cu() {
 void launch_pack_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles, const uint64_t* stats, Meta* meta) {
     hipLaunchKernelGGL(k_pack_i64, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles, stats, meta);
 }
-void launch_unpack_f32(hipStream_t s, int grid, bool narrow, const DevJob* jobs, int njobs, int64_t tiles) {
-    if (narrow) hipLaunchKernelGGL(k_unpack_f32<true>, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
-    else hipLaunchKernelGGL(k_unpack_f32<false>, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
+void launch_unpack_f32(hipStream_t s, int grid, bool narrow, bool xf, const DevJob* jobs, int njobs, int64_t tiles) {
+    if (narrow) {
+        if (xf) hipLaunchKernelGGL((k_unpack_f32<true, true>), dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
+        else hipLaunchKernelGGL((k_unpack_f32<true, false>), dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
+    } else {
+        if (xf) hipLaunchKernelGGL((k_unpack_f32<false, true>), dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
+        else hipLaunchKernelGGL((k_unpack_f32<false, false>), dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);
+    }
 }
 void launch_unpack_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t tiles) {
     hipLaunchKernelGGL(k_unpack_i64, dim3(grid), dim3(kThreads), 0, s, jobs, njobs, tiles);

@@ -142,6 +142,8 @@ def test_transform_inside_the_codec_jobs(mnw, oracle, torch_mod, mode):
     neg = (10 ** rng.uniform(9, 12, 30000)).astype(np.float32); neg[5] = -3.0            # log10(<0) = NaN -> exact path
     cols.append((mnw.XF_LOG10 | mnw.XF_CLAMP, 8.0, 16.0, 0.01, neg))
     cols.append((0, 0.0, 250.0, 0.001, np.mod(125 + 20 * rng.standard_normal(50000), 250).astype(np.float32)))   # plain
+    # a ring of more than 2^31 pixels: the 64-bit decode class (and the exact encode path), with the reader's 10^x
+    cols.append((mnw.XF_LOG10 | mnw.XF_CLAMP, 8.0, 16.0, 1e-9, (10 ** rng.uniform(8.5, 15.5, 7001)).astype(np.float32)))
     with mnw.Context(0) as c:
         if mode == "two_pass":
             c.set_option("single_read", 0)
@@ -169,8 +171,24 @@ def test_transform_inside_the_codec_jobs(mnw, oracle, torch_mod, mode):
             assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), b
             djobs.append(mnw.DecJob(o.data_ptr(), y.data_ptr(), x.size, m.nbytes, m.min, m.bits, mnw.FLOAT_GROUP, lo, hi, p, 1,
                                     seed=3, block=b, xform=xf & mnw.XF_LOG10))
+        c.timing_reset()
         c.decode_blocks(djobs)
         torch.cuda.synchronize()
+        # the reader's 10^x (go/minh/minh.go:315-319) happens inside the unpack kernel; as a pass of its own (unlog_fused = 0) it
+        # gives the same floats
+        kt = c.timing_get()
+        assert kt["k_unpack_f32"]["launches"] == 2 and kt["k_minh_unlog"]["launches"] == 0      # narrow and wide decode classes
+        first = [y.clone() for y in ys]
+        c.set_option("unlog_fused", 0)
+        for y in ys:
+            y.zero_()
+        torch.cuda.synchronize()
+        c.decode_blocks(djobs)
+        torch.cuda.synchronize()
+        assert c.timing_get()["k_minh_unlog"]["launches"] >= 1
+        for a_, b_ in zip(first, ys):
+            assert torch.equal(a_.view(torch.int32), b_.view(torch.int32))
+        c.set_option("unlog_fused", 1)
         for b, ((xf, lo, hi, dx, x), m, o, y, p) in enumerate(zip(cols, metas, outs, ys, pix)):
             odata = o[: m.nbytes].cpu().numpy()
             ref = oracle.float_decode(odata, m.min, m.bits, lo, hi, p, True, x.size, u=oracle.dither(3, b, x.size), literal=False)

@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
         Meta m; CHK(hipMemcpy(&m, meta, sizeof m, hipMemcpyDeviceToHost));
         DevJob d2 = j; d2.src = out; d2.dst = y; d2.cap = m.nbytes; d2.min = m.min; d2.bits = (int)m.bits; d2.mode = kModeExplicit; d2.seed = 1;
         DevJob* dj2; CHK(hipMalloc(&dj2, sizeof(DevJob))); CHK(hipMemcpy(dj2, &d2, sizeof d2, hipMemcpyHostToDevice));
-        float t3 = timeit([&] { launch_unpack_f32(0, g, true, dj2, 1, tilesd); }, 10);
+        float t3 = timeit([&] { launch_unpack_f32(0, g, true, false, dj2, 1, tilesd); }, 10);
         printf("n=%ld grid=%4d reduce %.1f us (%.2f TB/s)  pack %.1f us (bits %ld, %.2f TB/s rd+wr)  unpack %.1f us (%.2f TB/s)\n", n, g,
                t1 * 1e3, n * 4 / t1 / 1e9, t2 * 1e3, (long)m.bits, (n * 4 + m.nbytes) / t2 / 1e9, t3 * 1e3, (n * 4 + m.nbytes) / t3 / 1e9);
         CHK(hipFree(dj2));

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     for (int g : {1024, 2048, 4096}) {
         float best = 1e9;
-        for (int r = 0; r < 6; ++r) { CHK(hipEventRecord(a)); launch_unpack_f32(0, g, true, dj, 1, tiles); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b)); float ms; CHK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms; }
+        for (int r = 0; r < 6; ++r) { CHK(hipEventRecord(a)); launch_unpack_f32(0, g, true, false, dj, 1, tiles); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b)); float ms; CHK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms; }
         printf("%s n=%ld grid=%d unpack %.1f us (%.2f TB/s)\n",
 #ifdef MNW_DIAG_NO_DITHER
                "NO-DITHER",
