@@ -2073,27 +2073,27 @@ __device__ __forceinline__ StreamView stream_view(const DevJob& jb, uint32_t b) 
     return v;
 }
 
-__device__ __forceinline__ uint64_t stream_word(const StreamView& sv, int64_t k) {
-    const uint64_t lo = k <= sv.last ? ldg<uint64_t>(sv.a + k) : 0;
-    if (sv.sh == 0) return lo;
-    const uint64_t hi = (k + 1) <= sv.last ? ldg<uint64_t>(sv.a + k + 1) : 0;
-    return (lo >> sv.sh) | (hi << (64 - sv.sh));
-}
-
-// words of one tile (kTileD elements = kTileD/64*b words, plus one look-ahead word) -> registers
+// The aligned words that hold one tile's bits (kTileD elements = kTileD/64*b words, one look-ahead word, one more for a stream
+// that starts inside a word) -> registers, exactly as they lie in memory: the stream's bit offset `sh` is added where the
+// elements are extracted, not shifted out here.  Nothing is computed on the loaded words and none is merged with a constant, so
+// all the loads of the tile are in flight together and across the extraction of the tile before (a word past the stream's end is
+// read as the last valid one: it only feeds elements beyond n, which are never stored).
 template <int NW>
 __device__ __forceinline__ void load_tile_words(uint64_t (&w)[NW], const StreamView& sv, int64_t base, uint32_t b) {
     const int64_t w0 = base / 64 * b;
-    const int nw = kTileD / 64 * (int)b + 1;
+    const int nw = kTileD / 64 * (int)b + 2;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int i = k * kThreads + (int)threadIdx.x;
-        w[k] = i < nw ? stream_word(sv, w0 + i) : 0;
+        if (i < nw) {
+            const int64_t kk = w0 + i;
+            w[k] = ldg<uint64_t>(sv.a + (kk < sv.last ? kk : sv.last));
+        }
     }
 }
 template <int NW>
 __device__ __forceinline__ void stage_tile_words(uint64_t* __restrict__ lw, const uint64_t (&w)[NW], uint32_t b) {
-    const int nw = kTileD / 64 * (int)b + 1;
+    const int nw = kTileD / 64 * (int)b + 2;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const int i = k * kThreads + (int)threadIdx.x;
@@ -2101,16 +2101,17 @@ __device__ __forceinline__ void stage_tile_words(uint64_t* __restrict__ lw, cons
     }
 }
 
+// element i of the staged tile; `sh` = bit offset of the stream inside the first staged word (StreamView::sh)
 __device__ __forceinline__ uint32_t extract32(const uint32_t* __restrict__ l32, uint32_t i, uint32_t b,
-                                              uint32_t mask) {
-    const uint32_t bitpos = i * b;
+                                              uint32_t mask, uint32_t sh0) {
+    const uint32_t bitpos = i * b + sh0;
     const uint32_t di = bitpos >> 5, sh = bitpos & 31;
     const uint64_t win = (uint64_t)l32[di] | ((uint64_t)l32[di + 1] << 32);
     return (uint32_t)(win >> sh) & mask;
 }
 __device__ __forceinline__ uint64_t extract64(const uint64_t* __restrict__ l64, uint32_t i, uint32_t b,
-                                              uint64_t mask) {
-    const uint32_t bitpos = i * b;
+                                              uint64_t mask, uint32_t sh0) {
+    const uint32_t bitpos = i * b + sh0;
     const uint32_t wi = bitpos >> 6, sh = bitpos & 63;
     uint64_t v = l64[wi] >> sh;
     if (sh != 0) v |= l64[wi + 1] << (64 - sh);
@@ -2173,7 +2174,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
                     const uint32_t i = i0 + c;
                     double qd;
                     if (NARROW) {
-                        const uint32_t v = b == 0 ? 0 : extract32(reinterpret_cast<const uint32_t*>(lw), i, b, (uint32_t)mask64);
+                        const uint32_t v = b == 0 ? 0 : extract32(reinterpret_cast<const uint32_t*>(lw), i, b, (uint32_t)mask64, sv.sh);
                         int32_t q = (int32_t)jb.min + (int32_t)v;            // group.go:262
                         if (per) {                                          // bound(buf, 0, pixels)
                             if (q < 0) q += (int32_t)jb.pixels;
@@ -2181,7 +2182,7 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
                         }
                         qd = (double)q;
                     } else {
-                        const uint64_t v = b == 0 ? 0 : extract64(lw, i, b, mask64);
+                        const uint64_t v = b == 0 ? 0 : extract64(lw, i, b, mask64, sv.sh);
                         int64_t q = (int64_t)((uint64_t)jb.min + v);
                         if (per) {
                             if (q < 0) q = (int64_t)((uint64_t)q + (uint64_t)jb.pixels);
@@ -2252,8 +2253,8 @@ __global__ __launch_bounds__(kThreads) void k_unpack_i64(const DevJob* __restric
 #pragma unroll
             for (int k = 0; k < kTileD / (2 * kThreads); ++k) {
                 const uint32_t i0 = 2 * (k * kThreads + tid);
-                const uint64_t v0 = b == 0 ? 0 : extract64(lw, i0, b, mask64);
-                const uint64_t v1 = b == 0 ? 0 : extract64(lw, i0 + 1, b, mask64);
+                const uint64_t v0 = b == 0 ? 0 : extract64(lw, i0, b, mask64, sv.sh);
+                const uint64_t v1 = b == 0 ? 0 : extract64(lw, i0 + 1, b, mask64, sv.sh);
                 i64x2 r;
                 r.x = (int64_t)(mn + v0);
                 r.y = (int64_t)(mn + v1);

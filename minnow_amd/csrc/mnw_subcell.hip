@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restri
                     for (int k = 0; k < 3; ++k) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const uint32_t val = b[k] == 0 ? 0u : extract32(reinterpret_cast<const uint32_t*>(lw[k]), e + c, b[k], mask[k]);
+                            const uint32_t val = b[k] == 0 ? 0u : extract32(reinterpret_cast<const uint32_t*>(lw[k]), e + c, b[k], mask[k], sv[k].sh);
                             int32_t q = mn[k] + (int32_t)val;                 // group.go:262
                             if (q < 0) q += pix[k];                           // bound(buf, 0, pixels): FloatGroups are periodic
                             else if (q >= pix[k]) q -= pix[k];
