@@ -964,8 +964,12 @@ __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restri
                             int32_t q = mn[k] + (int32_t)val;                 // group.go:262
                             if (q < 0) q += pix[k];                           // bound(buf, 0, pixels): FloatGroups are periodic
                             else if (q >= pix[k]) q -= pix[k];
+#ifdef MNW_DIAG_NO_DITHER      // diagnostic builds only: price the dither
+                            const double u = 0.0;
+#else
                             const uint32_t z = dither_bits(j + c, ka[k], kb[k]);
                             const double u = (double)z * (1.0 / 4294967296.0);
+#endif
                             const float x = __fadd_rn(__fmul_rn(dx[k], (float)__dadd_rn((double)q, u)), low[k]);   // group.go:308
                             o[k][c] = wrap_once(x, L, periodic);
                         }
