@@ -354,6 +354,8 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * big_blocks: 1 (default) = that includes blocks of more than 2^22 elements; 0 = those take reduce + pack.
  * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
  *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.
+ * reg_round_table: which built-in table of round sizes the weighted hand-out uses (0, default: the quarters of the grid take
+ *        14 / 12 / 11 / 10 items per cycle; 1..4: other ratios, kept for measurements -- none was faster).
  * reg_test_drop_item: test hook (default -1): the single-read kernel never publishes the statistics of that item, so
  *        the launch must give up after its 50 ms bound and the host must rerun the batch through reduce + pack.
  * vec3_fused: 1 (default) = mnw_vectors_encode reads the particle grid directly in its reduce and pack kernels

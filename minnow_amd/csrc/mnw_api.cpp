@@ -259,6 +259,7 @@ struct mnw_ctx {
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int reg_vec3_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_vec3 per CU
+    int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
     int vec3_single_read = 0;    // minp vectors: 1 = the grid is read once (k_encode_reg_vec3) when the geometry allows.  Opt-in: measured
                                  // no faster than k_reduce_vec3 + k_pack_vec3 on C4, and it needs its whole grid co-resident
@@ -886,14 +887,14 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         // block has more items than the grid has workgroups; group records live behind the item records
         mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs,
                                    (uint8_t*)c->d_recs + (size_t)items * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl), sl->d_hsync,
-                                   sl->d_meta, (grid == c->cus * 4 && !unweighted) ? c->reg_weighted : 0, c->reg_drop_item, any_xform,
+                                   sl->d_meta, (grid == c->cus * 4 && !unweighted && c->reg_weighted) ? 1 + c->reg_round_table : 0, c->reg_drop_item, any_xform,
                                    max_ni > mnw::reg_max_items_per_block() ? 1 : 0);
     }
     if (in && items_i > 0) {
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_I64);
         mnw::launch_encode_reg_i64(s, grid_i, sl->d_jobs + nfloat, nslot_all - nfloat, items_i, sl->d_itemjob + items_pad,
                                    (uint8_t*)c->d_recs + (size_t)(items + groups) * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl),
-                                   sl->d_hsync, sl->d_meta + nfloat, grid_i == c->cus * 4 ? c->reg_weighted : 0, c->reg_drop_item);
+                                   sl->d_hsync, sl->d_meta + nfloat, (grid_i == c->cus * 4 && c->reg_weighted) ? 1 + c->reg_round_table : 0, c->reg_drop_item);
     }
     HIPCHK(c, hipGetLastError());
     *did_float = fl; *did_int = in;
@@ -1078,6 +1079,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_read_int")) { c->single_read_int = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_single_read")) { c->vec3_single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "unlog_fused")) { c->unlog_fused = value != 0; return MNW_OK; }
+    if (!strcmp(name, "reg_round_table")) { if (value < 0 || value > 4) return fail(c, MNW_E_ARG, "reg_round_table: 0..4"); c->reg_round_table = (int)value; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_tiles_per_wg")) { c->vec3_tiles_per_wg = (int)value; return MNW_OK; }
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }

@@ -675,7 +675,11 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 __device__ int g_dbg_skip = 0;
 #define MNW_STAMP_DECL unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
 #define MNW_STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#ifdef MNW_STAMPS_LIGHT     // start and end of every workgroup only: the kernel as shipped but for two clock reads
+#define MNW_STAMP(i)
+#else
 #define MNW_STAMP(i) { unsigned long long t2_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc[i] += t2_ - st_t; st_t = t2_; }
+#endif
 #define MNW_STAMP_FLUSH if (g_stamp_buf && threadIdx.x == 0) { const unsigned long long e_ = __builtin_amdgcn_s_memrealtime(); st_acc[7] = e_ - st_rt0; st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0; for (int i_ = 0; i_ < 8; ++i_) g_stamp_buf[blockIdx.x * 8 + i_] += st_acc[i_]; if (g_stamp_abs) { g_stamp_abs[blockIdx.x * 2] = st_rt0; g_stamp_abs[blockIdx.x * 2 + 1] = e_; } }
 #else
 #define MNW_STAMP_DECL
@@ -1239,8 +1243,17 @@ __device__ __attribute__((noinline)) uint64_t block_desc_big_f32(const DevJob* _
 }
 
 // round sizes of the weighted item hand-out, in quarters of the grid (see k_encode_reg_f32)
-constexpr int kRounds = 14;
-__constant__ int kRoundQuarters[kRounds] = {4, 4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 2, 4};      // 14 / 12 / 11 / 10 items per cycle
+// (table 0 is the default; the others are there to be measured against it: option reg_round_table.  Every table starts with a
+// full round and has no two partial rounds adjacent, also around its end.)
+constexpr int kRoundTables = 5, kMaxRounds = 20;
+__constant__ int kRoundCount[kRoundTables] = {14, 16, 17, 15, 18};
+__constant__ int kRoundTable[kRoundTables][kMaxRounds] = {
+    {4, 4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 2, 4},                          // 14 / 12 / 11 / 10 items per cycle
+    {4, 1, 4, 3, 4, 2, 4, 1, 4, 3, 4, 2, 4, 1, 4, 4},                    // 16 / 13 / 11 / 9
+    {4, 1, 4, 3, 4, 2, 4, 1, 4, 3, 4, 2, 4, 1, 4, 4, 4},                 // 17 / 14 / 12 / 10
+    {4, 4, 1, 4, 4, 3, 4, 4, 1, 4, 4, 2, 4, 4, 4},                       // 15 / 13 / 12 / 11
+    {4, 1, 4, 2, 4, 3, 4, 1, 4, 2, 4, 3, 4, 1, 4, 2, 4, 1},              // 18 / 14 / 11 / 9
+};
 // (measured against 14/13/12/11, 14/14/12/11 and 14/11/10/9: within 1 % at 1e8 elements, best at 1e9)
 
 #ifdef MNW_STAMPS
@@ -1319,10 +1332,10 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     int64_t round_base = 0;
     auto next_item = [&]() -> int64_t {           // the workgroup's item after the one in (round, round_base)
         for (;;) {
-            round_base += (int64_t)(weighted ? kRoundQuarters[round] : 1) * unit;
-            round = round + 1 == kRounds ? 0 : round + 1;
+            round_base += (int64_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit;
+            round = round + 1 == (weighted ? kRoundCount[weighted - 1] : 1) ? 0 : round + 1;
             if (round_base >= total_items) return total_items;
-            if ((int)blockIdx.x < (weighted ? kRoundQuarters[round] : 1) * unit) return round_base + blockIdx.x;
+            if ((int)blockIdx.x < (weighted ? kRoundTable[weighted - 1][round] : 1) * unit) return round_base + blockIdx.x;
         }
     };
     int64_t it = blockIdx.x;                      // round 0 is a full one
@@ -1754,10 +1767,10 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
     int64_t round_base = 0;
     auto next_item = [&]() -> int64_t {
         for (;;) {
-            round_base += (int64_t)(weighted ? kRoundQuarters[round] : 1) * unit;
-            round = round + 1 == kRounds ? 0 : round + 1;
+            round_base += (int64_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit;
+            round = round + 1 == (weighted ? kRoundCount[weighted - 1] : 1) ? 0 : round + 1;
             if (round_base >= total_items) return total_items;
-            if ((int)blockIdx.x < (weighted ? kRoundQuarters[round] : 1) * unit) return round_base + blockIdx.x;
+            if ((int)blockIdx.x < (weighted ? kRoundTable[weighted - 1][round] : 1) * unit) return round_base + blockIdx.x;
         }
     };
     int64_t it = blockIdx.x;
@@ -2400,7 +2413,7 @@ size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
                            void* grecs, uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted,
                            int64_t test_drop_item, int any_xform, int big) {
-    const int w = (weighted && grid % 4 == 0) ? 1 : 0;
+    const int w = (weighted > 0 && weighted <= kRoundTables && grid % 4 == 0) ? weighted : 0;     // 1 + the round table
 #define MNW_LAUNCH_REG(XF, BIG) hipLaunchKernelGGL((k_encode_reg_f32<XF, BIG>), dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, \
                                                    (ItemRec*)recs, (ItemRec*)grecs, gen, abort_flag, abort_host, meta, w, test_drop_item)
     if (any_xform) { if (big) MNW_LAUNCH_REG(true, true); else MNW_LAUNCH_REG(true, false); }
@@ -2410,7 +2423,7 @@ void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njob
 void launch_encode_reg_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t drop_item) {
     hipLaunchKernelGGL(k_encode_reg_i64, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
-                       abort_flag, abort_host, meta, (weighted && grid % 4 == 0) ? 1 : 0, drop_item);
+                       abort_flag, abort_host, meta, (weighted > 0 && weighted <= kRoundTables && grid % 4 == 0) ? weighted : 0, drop_item);
 }
 int64_t reg_item_elems_i64() { return kItemI; }
 int encode_reg_i64_blocks_per_cu() {

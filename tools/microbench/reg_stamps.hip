@@ -17,7 +17,7 @@ __global__ void k_fill(float* x, long n) {
 int main(int argc, char** argv) {
     long n = argc > 1 ? atol(argv[1]) : 100000000L;
     long B = argc > 2 ? atol(argv[2]) : (1L << 20);
-    int grid = argc > 3 ? atoi(argv[3]) : 512;
+    int grid = argc > 3 ? atoi(argv[3]) : 1024;
     int skip = argc > 4 ? atoi(argv[4]) : 0;
     float* x; uint8_t* out; unsigned long long* sb;
     CHK(hipMalloc(&x, n * 4)); CHK(hipMalloc(&out, n * 4 + 64));
@@ -42,9 +42,9 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(dj, hj.data(), sizeof(DevJob) * nj, hipMemcpyHostToDevice)); CHK(hipMemset(recs, 0, sizeof(ItemRec) * items)); CHK(hipMemset(ab, 0, 128));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     uint32_t gen = 1;
-    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1, 0); }
+    for (int r = 0; r < 3; ++r) { CHK(hipMemset(ab, 0, 128)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, recs + items, gen++, ab, ab + 8, dm, 1, -1, 0, 0); }
     CHK(hipDeviceSynchronize()); CHK(hipMemset(sb, 0, 8 * 8 * 4096));
-    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, gen++, ab, ab + 8, dm, skip, -1, 0); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+    CHK(hipMemset(ab, 0, 128)); CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch_encode_reg_f32(0, grid, dj, nj, items, ij, recs, recs + items, gen++, ab, ab + 8, dm, 1, -1, 0, 0); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
     float ms; CHK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> h(8 * grid); CHK(hipMemcpy(h.data(), sb, 8 * 8 * grid, hipMemcpyDeviceToHost));
     Meta m0; CHK(hipMemcpy(&m0, dm, sizeof m0, hipMemcpyDeviceToHost)); uint32_t abv; CHK(hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost));
