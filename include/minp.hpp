@@ -69,7 +69,22 @@ struct DevBuf {                              // grow-only device buffer
     }
 };
 inline size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+// Scratch that outlives the Writer / Reader objects: one object per file is the reference's usage (minp.go:64, 141), and a
+// snapshot is hundreds of files -- buffers owned by the object would be allocated, page-faulted in (0.1 s per GB of host memory)
+// and freed again for every file.  Per thread, grow-only, used only inside one Vectors call; ReleaseScratch() gives it back.
+struct Scratch {
+    DevBuf grid, streams;
+    minnow::detail::RawBuf host;
+};
+inline Scratch& scratch() { static thread_local Scratch s; return s; }
 }  // namespace detail
+inline void ReleaseScratch() {
+    detail::Scratch& s = detail::scratch();
+    if (s.grid.p) { mnw_dev_free(minnow::detail::ctx(), s.grid.p); s.grid.p = nullptr; s.grid.cap = 0; }
+    if (s.streams.p) { mnw_dev_free(minnow::detail::ctx(), s.streams.p); s.streams.p = nullptr; s.streams.cap = 0; }
+    s.host.p.reset(); s.host.cap = 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // minp.Writer, minp.go:55-123
@@ -94,7 +109,7 @@ class Writer {
     // Vectors, minp.go:86-119: vec = [n][3]float32 on the host
     void Vectors(const float* vec, size_t n) {
         mnw_ctx* ctx = minnow::detail::ctx();
-        float* d = reinterpret_cast<float*>(grid_.get(n * 12 + 16));
+        float* d = reinterpret_cast<float*>(detail::scratch().grid.get(n * 12 + 16));
         minnow::detail::check(mnw_copy_to_device(ctx, d, vec, (int64_t)(n * 12)));
         VectorsDevice(d, n);
     }
@@ -123,7 +138,7 @@ class Writer {
         uint8_t* dst = nullptr;
         for (int wide = 0;; ++wide) {        // 32 bits per element hold any block of a sane column; a NaN needs up to 64 (see minh.hpp)
             slot = detail::align16((size_t)(wide ? 8 : 4) * (size_t)nSub3 + 16);
-            dst = streams_.get(slot * (size_t)(3 * subCells3));
+            dst = detail::scratch().streams.get(slot * (size_t)(3 * subCells3));
             const int rc = mnw_vectors_encode(ctx, nullptr, dvec, nFile, subCells, mn, mx, pixels, dst, (int64_t)slot, meta.data());
             if (rc == MNW_E_CAPACITY && !wide) continue;
             minnow::detail::check(rc);
@@ -133,7 +148,7 @@ class Writer {
         const size_t nb = (size_t)(3 * subCells3);
         std::vector<size_t> at(nb + 1, 0);
         for (size_t b = 0; b < nb; ++b) at[b + 1] = at[b] + (((size_t)meta[b].nbytes + 63) & ~(size_t)63);
-        uint8_t* const hraw = raw_.get(at[nb] + 64);
+        uint8_t* const hraw = detail::scratch().host.get(at[nb] + 64);
         {
             std::vector<void*> d(nb);
             std::vector<const void*> sp(nb);
@@ -159,9 +174,6 @@ class Writer {
     minp::Header hd_;
     bool periodic_ = false;
     float dx_ = 0;
-    detail::DevBuf grid_, streams_;
-    std::vector<uint8_t> host_;
-    minnow::detail::RawBuf raw_;
 };
 inline std::unique_ptr<Writer> Create(const std::string& fname) { return std::make_unique<Writer>(fname); }
 
@@ -199,7 +211,7 @@ class Reader {
     void Vectors(float* out) {
         const int nFile = c_.NFile((int)Header.NSide);
         const size_t n = (size_t)nFile * nFile * nFile;
-        float* d = reinterpret_cast<float*>(grid_.get(n * 12 + 16));
+        float* d = reinterpret_cast<float*>(detail::scratch().grid.get(n * 12 + 16));
         VectorsDevice(d);
         minnow::detail::check(mnw_copy_to_host(minnow::detail::ctx(), out, d, (int64_t)(n * 12)));
     }
@@ -231,12 +243,12 @@ class Reader {
             }
         }
         const size_t hostBytes = slot * (size_t)(3 * subCells3);
-        uint8_t* const hsrc = rawR_.get(hostBytes + 64);
+        uint8_t* const hsrc = detail::scratch().host.get(hostBytes + 64);
         for (int64_t b = 0; b < 3 * subCells3; ++b) {
             std::fseek(f_->File(), (long)f_->BlockFileOffset((int)b), SEEK_SET);
             minnow::detail::fread_all(f_->File(), hsrc + (size_t)b * slot, (size_t)meta[(size_t)b].nbytes);
         }
-        uint8_t* dsrc = streams_.get(hostBytes + 16);
+        uint8_t* dsrc = detail::scratch().streams.get(hostBytes + 16);
         minnow::detail::check(mnw_copy_to_device(ctx, dsrc, hsrc, (int64_t)hostBytes));
         minnow::detail::check(mnw_vectors_decode(ctx, nullptr, dsrc, (int64_t)slot, meta.data(), nFile, subCells, low, high, pixels,
                                                  Periodic ? 1 : 0, (float)Header.L, DitherSeed, 0, dout));
@@ -262,9 +274,6 @@ class Reader {
    private:
     std::unique_ptr<minnow::Reader> f_;
     Cell c_;
-    detail::DevBuf grid_, streams_;
-    std::vector<uint8_t> host_;
-    minnow::detail::RawBuf rawR_;
 };
 inline std::unique_ptr<Reader> Open(const std::string& fname) { return std::make_unique<Reader>(fname); }
 
