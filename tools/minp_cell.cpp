@@ -64,6 +64,7 @@ int main(int argc, char** argv) {
             // (a) from host memory, as the reference's caller has it; twice, the second timed (buffers and tables exist by then)
             double t_write_host = 0, t_write_dev = 0;
             for (int rep = 0; rep < 2; ++rep) {
+                std::remove(fhost.c_str());              // (a new file each time: overwriting an existing one is 2.5x slower on this file system)
                 const double t0 = now();
                 minp::Writer w(fhost);
                 w.Header(hd, raw, cell, dx, periodic);
@@ -74,6 +75,7 @@ int main(int argc, char** argv) {
             // (b) from a grid that is on the device already
             minnow::detail::check(mnw_copy_to_device(ctx, dgrid, src.data(), (int64_t)(n * 12)));
             for (int rep = 0; rep < 2; ++rep) {
+                std::remove(fdev.c_str());
                 const double t0 = now();
                 minp::Writer w(fdev);
                 w.Header(hd, raw, cell, dx, periodic);
