@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 
 #include "minnow.hpp"
 
@@ -317,7 +318,9 @@ class Reader {
     float L = 0, Boundary = 0;
     int Cells = 0;
     uint64_t DitherSeed = 0;       // replaces the unseeded global math/rand of group.go:308 (DESIGN.md "Dither")
+    bool ReadAhead = true;         // prefetch the next block's streams of the columns just asked for (see blockImpl)
 
+    ~Reader() { stopAhead(); }
     // Open, minh.go:184-236
     explicit Reader(const std::string& fname) : f_(minnow::Open(fname)) {
         idHeader hd;
@@ -393,7 +396,7 @@ class Reader {
         return out;
     }
 
-    void Close() { f_->Close(); }                                  // minh.go:325-327
+    void Close() { stopAhead(); f_->Close(); }                     // minh.go:325-327
 
    private:
     int findName(const std::string& name) const {                  // minh.go:329-334
@@ -436,14 +439,25 @@ class Reader {
             total += nb;
         }
         if (codec.empty()) return;
-        // the streams of the requested columns: file -> one staging buffer -> device, then one batch of decode jobs
-        uint8_t* const hraw = rawHost_.get(total + 1);
-        for (const Item& it : codec) {
-            std::fseek(f_->File(), (long)f_->BlockFileOffset(it.idx), SEEK_SET);
-            minnow::detail::fread_all(f_->File(), hraw + it.off, it.nbytes);
+        // The streams of the requested columns: file -> one staging buffer -> device, then one batch of decode jobs.  A file is
+        // normally read front to back with the same columns for every block (minh.go's callers loop over rd.Blocks): while this
+        // block is decoded, a thread already reads the same columns of block b + 1 and uploads them through a context of its
+        // own; the call for b + 1 finds its streams on the device.  Anything else simply misses the prefetch.
+        std::vector<int> key;
+        key.reserve(codec.size());
+        for (const Item& it : codec) key.push_back(it.c);
+        Ahead& ah = ahead_[ints ? 1 : 0];
+        uint8_t* dstage = nullptr;
+        if (ah.join() && ah.ready && ah.b == b && ah.cols == key && ah.total == total) {
+            dstage = static_cast<uint8_t*>(ah.dev[ah.cur]);
+        } else {
+            std::vector<int64_t> foff, flen;
+            for (const Item& it : codec) { foff.push_back(f_->BlockFileOffset(it.idx)); flen.push_back((int64_t)it.nbytes); }
+            dstage = stage_.get(total + 64);
+            minnow::detail::check(mnw_copy_file_to_device(ctx, dstage, fileno(f_->File()), (int)foff.size(), foff.data(), flen.data(), nullptr));
         }
-        uint8_t* dstage = stage_.get(total + 64);
-        minnow::detail::check(mnw_copy_to_device(ctx, dstage, hraw, (int64_t)total));
+        ah.ready = false;
+        if (ReadAhead && b + 1 < Blocks) startAhead(ah, b + 1, key, ints);
         uint8_t* dout = onDevice ? nullptr : outs_.get(codec.size() * detail::align16(N * esz));
         std::vector<mnw_dec_job> jobs;
         for (size_t k = 0; k < codec.size(); ++k) {
@@ -479,6 +493,71 @@ class Reader {
                 minnow::detail::check(mnw_copy_to_host(ctx, codec[k].out, dout + k * detail::align16(N * esz), (int64_t)(N * esz)));
         }
     }
+
+    // ---- read-ahead of the next block's streams (one slot for IntBlock requests, one for FloatBlock requests) ----
+    struct Ahead {
+        std::thread th;
+        bool ready = false;
+        int b = -1;
+        std::vector<int> cols;
+        size_t total = 0;
+        int cur = 0;                                   // which of the two device buffers the finished prefetch is in
+        void* dev[2] = {nullptr, nullptr};
+        size_t cap[2] = {0, 0};
+        bool join() { if (th.joinable()) th.join(); return true; }
+    };
+    void startAhead(Ahead& ah, int b, const std::vector<int>& cols, bool ints) {
+        // the request for block b, worked out here (the group tables are not touched by the thread)
+        struct Piece { int64_t fileOff; size_t off, nbytes; };
+        std::vector<Piece> pieces;
+        size_t total = 0;
+        const size_t N = (size_t)BlockLengths[(size_t)b];
+        if (N == 0) return;
+        for (int c : cols) {
+            const int idx = fileType_ == basicFileType ? c + b * (int)Columns.size() : c * Blocks + b;
+            minnow::intGroup* ig = intGroupOf(idx);
+            const int64_t bits = ig->bits.at((size_t)(idx - (int)ig->idx.startBlock));
+            const size_t nb = bits == 0 ? 0 : (size_t)minnow::bit::ArrayBytes((int)bits, (int)N);
+            pieces.push_back({f_->BlockFileOffset(idx), total, nb});
+            total += nb;
+        }
+        if (total == 0) return;
+        ah.b = b; ah.cols = cols; ah.total = total; ah.ready = false;
+        const int slot = ah.cur ^ 1;                   // the other buffer: the caller may still be decoding from dev[cur]
+        const int fd = fileno(f_->File());
+        (void)ints;
+        ah.th = std::thread([this, &ah, pieces, total, slot, fd] {
+            try {
+                std::lock_guard<std::mutex> lk(upMu_);              // one upload at a time through the second context
+                if (!upCtx_) {
+                    const char* dev = std::getenv("MNW_DEVICE");
+                    if (mnw_ctx_create(dev ? std::atoi(dev) : 0, &upCtx_) != MNW_OK) { upCtx_ = nullptr; return; }
+                }
+                if (ah.cap[slot] < total + 64) {
+                    if (ah.dev[slot]) mnw_dev_free(upCtx_, ah.dev[slot]);
+                    ah.dev[slot] = nullptr; ah.cap[slot] = 0;
+                    const size_t want = total + total / 4 + 256;
+                    if (mnw_dev_alloc(upCtx_, (int64_t)want, &ah.dev[slot]) != MNW_OK) return;
+                    ah.cap[slot] = want;
+                }
+                std::vector<int64_t> foff, flen;
+                for (const Piece& p : pieces) { foff.push_back(p.fileOff); flen.push_back((int64_t)p.nbytes); }
+                if (mnw_copy_file_to_device(upCtx_, ah.dev[slot], fd, (int)foff.size(), foff.data(), flen.data(), nullptr) != MNW_OK) return;
+                ah.cur = slot;
+                ah.ready = true;                                     // (read by the owner only after join())
+            } catch (...) {}
+        });
+    }
+    void stopAhead() {
+        for (Ahead& ah : ahead_) {
+            ah.join();
+            for (int k = 0; k < 2; ++k) if (ah.dev[k]) { mnw_dev_free(upCtx_ ? upCtx_ : minnow::detail::ctx(), ah.dev[k]); ah.dev[k] = nullptr; }
+        }
+        if (upCtx_) { mnw_ctx_destroy(upCtx_); upCtx_ = nullptr; }
+    }
+    Ahead ahead_[2];
+    std::mutex upMu_;
+    mnw_ctx* upCtx_ = nullptr;
 
     minnow::intGroup* intGroupOf(int idx) {
         minnow::group* g = f_->Group(f_->GroupOf(idx));

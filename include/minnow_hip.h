@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MNW_ABI_VERSION 4   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get; 4: MNW_K_COUNT 21 (k_encode_reg_i64, k_encode_reg_vec3) */
+#define MNW_ABI_VERSION 5   /* 2: xform field in mnw_enc_job / mnw_dec_job; 3: mnw_counters_get; 4: MNW_K_COUNT 21 (k_encode_reg_i64, k_encode_reg_vec3); 5: mnw_copy_file_to_device */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define MNW_OK            0
@@ -266,6 +266,12 @@ int mnw_text_stats(mnw_ctx *ctx, int64_t out[3]);
 int mnw_dev_alloc(mnw_ctx *ctx, int64_t nbytes, void **dev_ptr);
 int mnw_dev_free(mnw_ctx *ctx, void *dev_ptr);
 int mnw_copy_to_device(mnw_ctx *ctx, void *dev_dst, const void *host_src, int64_t nbytes);
+/* n byte ranges of an open file (descriptor fd; pread, the descriptor's position is not touched) into a device buffer: range i goes to
+ * dev_dst + dst_offsets[i], or, with dst_offsets NULL, the ranges are packed back to back in the order given.  The block streams a
+ * reader fetches (reader.go:121-126 `f.Read` per block), here for many blocks at once: the library's host threads read straight into
+ * its pinned buffers while earlier chunks are on the link.  Synchronous. */
+int mnw_copy_file_to_device(mnw_ctx *ctx, void *dev_dst, int fd, int n, const int64_t *file_offsets, const int64_t *nbytes,
+                            const int64_t *dst_offsets);
 int mnw_copy_to_host(mnw_ctx *ctx, void *host_dst, const void *dev_src, int64_t nbytes);
 /* n device -> host copies as one pipelined transfer through the library's pinned buffers (the streams of all columns of a
  * minh block, the blocks of a minp file): host_dst[i] receives nbytes[i] bytes from dev_src[i].  Synchronous. */

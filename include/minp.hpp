@@ -242,14 +242,18 @@ class Reader {
                 slot = std::max(slot, detail::align16((size_t)m.nbytes + 16));
             }
         }
+        // the file's ranges go to the device through the library's pinned buffers (no host copy in between), each to its slot
         const size_t hostBytes = slot * (size_t)(3 * subCells3);
-        uint8_t* const hsrc = detail::scratch().host.get(hostBytes + 64);
-        for (int64_t b = 0; b < 3 * subCells3; ++b) {
-            std::fseek(f_->File(), (long)f_->BlockFileOffset((int)b), SEEK_SET);
-            minnow::detail::fread_all(f_->File(), hsrc + (size_t)b * slot, (size_t)meta[(size_t)b].nbytes);
-        }
         uint8_t* dsrc = detail::scratch().streams.get(hostBytes + 16);
-        minnow::detail::check(mnw_copy_to_device(ctx, dsrc, hsrc, (int64_t)hostBytes));
+        {
+            std::vector<int64_t> foff, flen, doff;
+            for (int64_t b = 0; b < 3 * subCells3; ++b) {
+                foff.push_back(f_->BlockFileOffset((int)b));
+                flen.push_back(meta[(size_t)b].nbytes);
+                doff.push_back((int64_t)((size_t)b * slot));
+            }
+            minnow::detail::check(mnw_copy_file_to_device(ctx, dsrc, fileno(f_->File()), (int)foff.size(), foff.data(), flen.data(), doff.data()));
+        }
         minnow::detail::check(mnw_vectors_decode(ctx, nullptr, dsrc, (int64_t)slot, meta.data(), nFile, subCells, low, high, pixels,
                                                  Periodic ? 1 : 0, (float)Header.L, DitherSeed, 0, dout));
         uint8_t one;                                                     // a copy on the context's stream = wait for the decode

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mnw_dev_alloc": (_int, [_p, _i64, C.POINTER(_p)]),
     "mnw_dev_free": (_int, [_p, _p]),
     "mnw_copy_to_device": (_int, [_p, _p, _p, _i64]),
+    "mnw_copy_file_to_device": (_int, [_p, _p, _int, _int, _p, _p, _p]),
     "mnw_copy_to_host": (_int, [_p, _p, _p, _i64]),
     "mnw_copy_to_host_batch": (_int, [_p, _int, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i64)]),
     "mnw_generic_cut": (_int, [_p, _p, _p, C.c_float, _i64, C.POINTER(CutColC), _int, C.POINTER(_i64)]),

@@ -17,6 +17,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <cerrno>
+#include <unistd.h>
+#include <functional>
 #include <vector>
 
 namespace mnw {
@@ -137,7 +140,9 @@ struct CopyPool {                  // a fixed set of threads that split one memc
     int parts = 0, next_part = 0, done_parts = 0;
     uint64_t epoch = 0;
     bool quit = false;
+    const std::function<void(int)>* task = nullptr;     // set: part k runs (*task)(k); else it is a slice of one memcpy
     void part(int k) {
+        if (task) { (*task)(k); return; }
         const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
         const size_t a = per * k, b = a + per < n ? a + per : n;
         if (a < b) memcpy(dst + a, src + a, b - a);
@@ -157,9 +162,26 @@ struct CopyPool {                  // a fixed set of threads that split one memc
         }
     }
     void start(int threads) { for (int i = 0; i < threads; ++i) th.emplace_back([this] { worker(); }); }
+    // nparts independent pieces of work, fn(k) for k in [0, nparts), shared between the pool's threads and the caller
+    void run(int nparts, const std::function<void(int)>& fn) {
+        if (nparts <= 0) return;
+        if (th.empty() || nparts == 1) { for (int k = 0; k < nparts; ++k) fn(k); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        task = &fn;
+        parts = nparts; next_part = 0; done_parts = 0; ++epoch;
+        cv_go.notify_all();
+        while (next_part < parts) {
+            const int k = next_part++;
+            lk.unlock(); part(k); lk.lock();
+            ++done_parts;
+        }
+        cv_done.wait(lk, [&] { return done_parts == parts; });
+        task = nullptr;
+    }
     void copy(void* d, const void* s2, size_t bytes) {
         if (bytes < (1u << 20) || th.empty()) { memcpy(d, s2, bytes); return; }
         std::unique_lock<std::mutex> lk(mu);
+        task = nullptr;
         dst = (uint8_t*)d; src = (const uint8_t*)s2; n = bytes;
         parts = (int)th.size() + 1; next_part = 0; done_parts = 0; ++epoch;
         cv_go.notify_all();
@@ -437,6 +459,66 @@ int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t b
         g.busy[b] = true;
     }
     return MNW_OK;
+}
+
+// n ranges of a file -> one contiguous device buffer (in the order given), through the pinned ring: the host threads pread the
+// pieces of chunk k+1 straight into a pinned buffer while the DMA engine moves chunk k -- no pageable buffer in between, no
+// page faults, no second host copy.
+int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const int64_t* file_off, const int64_t* len, const int64_t* dst_off) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)len[i];
+    if (total == 0) return MNW_OK;
+    int rc = stager_init(c);
+    if (rc) return rc;
+    Stager& g = c->stg;
+    struct Piece { int64_t foff; size_t len, at, doff; };
+    const size_t kSub = 1u << 20;                             // pieces are cut to 1 MiB so that the threads share a chunk evenly
+    std::vector<Piece> cur;
+    size_t fill = 0;
+    std::string err;
+    std::mutex emu;
+    auto flush = [&]() -> int {
+        if (cur.empty()) return MNW_OK;
+        const int b = g.next; g.next = (g.next + 1) % Stager::kBufs;
+        if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
+        uint8_t* const pin = g.pin[b];
+        const std::function<void(int)> fn = [&](int k) {
+            const Piece& p = cur[(size_t)k];
+            size_t got = 0;
+            while (got < p.len) {
+                const ssize_t r = pread(fd, pin + p.at + got, p.len - got, (off_t)(p.foff + (int64_t)got));
+                if (r <= 0) { std::lock_guard<std::mutex> lk(emu); err = r == 0 ? "unexpected end of file" : strerror(errno); return; }
+                got += (size_t)r;
+            }
+        };
+        g.pool->run((int)cur.size(), fn);
+        if (!err.empty()) return fail(c, MNW_E_ARG, ("copy_file_to_device: " + err).c_str());
+        // one DMA per run of pieces that are contiguous in the destination as well (they are in the pinned buffer by construction)
+        for (size_t k = 0; k < cur.size();) {
+            size_t k2 = k + 1, run = cur[k].len;
+            while (k2 < cur.size() && cur[k2].doff == cur[k].doff + run) { run += cur[k2].len; ++k2; }
+            HIPCHK(c, hipMemcpyAsync((uint8_t*)dev_dst + cur[k].doff, pin + cur[k].at, run, hipMemcpyHostToDevice, s));
+            k = k2;
+        }
+        HIPCHK(c, hipEventRecord(g.ev[b], s));
+        g.busy[b] = true;
+        fill = 0; cur.clear();
+        return MNW_OK;
+    };
+    size_t packed = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t d0 = dst_off ? (size_t)dst_off[i] : packed;
+        size_t off = 0;
+        while (off < (size_t)len[i]) {
+            size_t take = std::min((size_t)len[i] - off, g.chunk - fill);
+            if (take > kSub) take = kSub;
+            cur.push_back(Piece{file_off[i] + (int64_t)off, take, fill, d0 + off});
+            off += take; fill += take;
+            if (fill == g.chunk) { rc = flush(); if (rc) return rc; }
+        }
+        packed += (size_t)len[i];
+    }
+    return flush();
 }
 
 // n device -> host copies, pipelined through the pinned ring: every pinned chunk is filled by as many pieces as fit, the DMA of
@@ -2040,6 +2122,16 @@ int mnw_copy_to_device(mnw_ctx* c, void* dst, const void* src, int64_t nbytes) {
     if (nbytes == 0) return MNW_OK;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = copy_h2d(c, c->stream, dst, src, (size_t)nbytes);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MNW_OK;
+}
+int mnw_copy_file_to_device(mnw_ctx* c, void* dst, int fd, int n, const int64_t* file_offsets, const int64_t* nbytes, const int64_t* dst_offsets) {
+    if (!c || n < 0 || fd < 0 || (n > 0 && (!dst || !file_offsets || !nbytes))) return fail(c, MNW_E_ARG, "copy_file_to_device: bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (nbytes[i] < 0 || file_offsets[i] < 0 || (dst_offsets && dst_offsets[i] < 0)) return fail(c, MNW_E_ARG, "copy_file_to_device: negative offset or size");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = copy_file_h2d(c, c->stream, dst, fd, n, file_offsets, nbytes, dst_offsets);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MNW_OK;

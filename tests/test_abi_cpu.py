@@ -35,7 +35,7 @@ def test_header_symbols_all_exported(mnw):
 
 def test_abi_version_and_strerror(mnw):
     L = mnw.lib()
-    assert L.mnw_abi_version() == 4
+    assert L.mnw_abi_version() == 5
     assert b"ok" == L.mnw_strerror(0)
     assert b"fallback" in L.mnw_strerror(-3)
 

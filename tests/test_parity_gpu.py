@@ -5,6 +5,7 @@ reference's own criterion |x - x'| <= dx (go/minnow_test.go:328-334).
 
 Nothing here reads /root/reference: inputs are seeded or come from tests/golden/.
 """
+import os
 import numpy as np
 import pytest
 
@@ -1180,3 +1181,41 @@ def test_1e9_column_in_2p24_blocks_sampled(mnw, oracle, torch_mod):
     nblk = (N + B - 1) // B
     blocks = sorted(set(range(0, nblk, 7)) | {0, nblk - 1})
     assert _headline_check(mnw, oracle, torch_mod, N, B, blocks) == 60
+
+
+def test_copy_file_to_device(mnw, ctx, torch_mod, tmp_path):
+    """mnw_copy_file_to_device: byte ranges of a file (what a reader fetches block by block, reader.go:121-126) into a device
+    buffer, packed and at given offsets; ranges larger than a pinned chunk, empty ranges, a range past the end of the file."""
+    import ctypes as C
+    torch = torch_mod
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, size=45_000_001, dtype=np.uint8)
+    fn = tmp_path / "ranges.bin"
+    data.tofile(fn)
+    fd = os.open(fn, os.O_RDONLY)
+    try:
+        offs = [0, 17, 1_000_003, 20_000_000, 44_999_990, 5]
+        lens = [1, 4_000_001, 0, 24_999_990, 11, 19_000_000]
+        A = lambda v: (C.c_int64 * len(v))(*v)
+        dev = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev.data_ptr()), fd, len(offs), A(offs), A(lens), None) == 0
+        want = np.concatenate([data[o:o + n] for o, n in zip(offs, lens)])
+        got = dev.cpu().numpy()
+        assert np.array_equal(got[: want.size], want) and not got[want.size:].any()
+        # destination offsets: gaps stay untouched
+        doff, at = [], 100
+        for n in lens:
+            doff.append(at); at += n + 37
+        dev2 = torch.full((at + 64,), 255, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev2.data_ptr()), fd, len(offs), A(offs), A(lens), A(doff)) == 0
+        got = dev2.cpu().numpy()
+        ref = np.full(at + 64, 255, dtype=np.uint8)
+        for o, n, d in zip(offs, lens, doff):
+            ref[d:d + n] = data[o:o + n]
+        assert np.array_equal(got, ref)
+        # past the end of the file: an error, not a short copy
+        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev.data_ptr()), fd, 1, A([44_999_000]), A([5000]), None) != 0
+    finally:
+        os.close(fd)
