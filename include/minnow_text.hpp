@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <memory>
+#include <chrono>
 #include <thread>
 #include "minnow.hpp"
 
@@ -39,6 +40,7 @@ struct BlockColumns {
 
 class Reader {
    public:
+    double UploadWaitSeconds = 0, UploadSeconds = 0;   // time Block spent waiting for the read-ahead thread / that thread's own time (diagnostics)
     // Open / openFromReader, text.go:42-67
     explicit Reader(const std::string& fname, ReaderConfig config = ReaderConfig()) : config_(config) {
         if (config_.MaxBlockSize / 2 < config_.MaxItemSize)
@@ -161,7 +163,12 @@ class Reader {
         }
         return up;
     }
-    void joinUpload() { if (upThread_.joinable()) upThread_.join(); }
+    void joinUpload() {
+        if (!upThread_.joinable()) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        upThread_.join();
+        UploadWaitSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     void startUpload(int b) {
         joinUpload();
         pending_.reset(new Upload());
@@ -172,6 +179,8 @@ class Reader {
         const int slot = upNext_;
         upNext_ ^= 1;
         upThread_ = std::thread([this, up, fd, off, len, slot] {
+            const auto t0 = std::chrono::steady_clock::now();
+            struct Fin { Reader* r; std::chrono::steady_clock::time_point t; ~Fin() { r->UploadSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } fin{this, t0};
             try {
                 up->block.reset(new Mapped(fd, off, len));
                 if (!upCtx_) {
@@ -186,7 +195,9 @@ class Reader {
                     if (mnw_dev_alloc(upCtx_, (int64_t)want, &upBuf_[slot]) != MNW_OK) return;
                     upCap_[slot] = want;
                 }
-                if (mnw_copy_to_device(upCtx_, upBuf_[slot], up->block->data, len) != MNW_OK) return;
+                // (straight from the file into the library's pinned buffers: reading the mapping instead costs a page-cache -> pinned
+                // memcpy of the whole block, which, not the link, then sets the converter's pace)
+                if (mnw_copy_file_to_device(upCtx_, upBuf_[slot], fd, 1, &off, &len, nullptr) != MNW_OK) return;
                 up->dev = static_cast<const uint8_t*>(upBuf_[slot]);
             } catch (const std::exception& e) { up->err = e.what(); }
         });
@@ -277,6 +288,8 @@ inline std::unique_ptr<Reader> Open(const std::string& fname, ReaderConfig confi
 class Rockstar {
    public:
     explicit Rockstar(const std::string& fname, ReaderConfig config = ReaderConfig()) : rd_(Open(fname, config)) {}
+    double UploadWaitSeconds() const { return rd_->UploadWaitSeconds; }             // (diagnostics: see Reader)
+    double UploadSeconds() const { return rd_->UploadSeconds; }
     // Names, rockstar.go:16-23: the column names in the first line of the file
     std::vector<std::string> Names() {
         const std::string firstLine = rd_->LineHeader(1);

@@ -19,6 +19,7 @@
 #include <thread>
 #include <cerrno>
 #include <unistd.h>
+#include <sched.h>
 #include <functional>
 #include <vector>
 
@@ -419,7 +420,14 @@ int stager_init(mnw_ctx* c) {
         HIPCHK(c, hipEventCreateWithFlags(&g.ev[b], hipEventDisableTiming));
     }
     int t = c->host_threads;
-    if (t <= 0) { const unsigned hw = std::thread::hardware_concurrency(); t = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1); }
+    if (t <= 0) { const char* e = getenv("MNW_HOST_THREADS"); if (e) t = atoi(e); }      // (for contexts a caller does not create itself)
+    if (t <= 0) {
+        // the CPUs this process may run on, not the machine's (a container's share is what counts)
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0 && (unsigned)n < hw) hw = (unsigned)n; }
+        t = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
+    }
     g.pool = new CopyPool();
     g.pool->start(t - 1);
     g.ready = true;

@@ -207,8 +207,8 @@ int main(int argc, char** argv) {
         const long outBytes = std::ftell(fo);
         std::fclose(fo);
         std::printf("{\"text_bytes\": %lld, \"blocks\": %d, \"rows\": %lld, \"rows_kept\": %lld, \"minh_bytes\": %ld, \"total_s\": %.6f, "
-                    "\"block_s\": %.6f, \"cut_s\": %.6f, \"minh_block_s\": %.6f, \"text_GBps\": %.4f, \"kernel_ms\": {%s}, \"kernels_total_ms\": %.4f}\n",
-                    (long long)bytesIn, fR->Blocks(), (long long)rowsIn, (long long)rowsKept, outBytes, total, tParse, tCut, tWrite,
+                    "\"block_s\": %.6f, \"upload_wait_s\": %.6f, \"upload_thread_s\": %.6f, \"cut_s\": %.6f, \"minh_block_s\": %.6f, \"text_GBps\": %.4f, \"kernel_ms\": {%s}, \"kernels_total_ms\": %.4f}\n",
+                    (long long)bytesIn, fR->Blocks(), (long long)rowsIn, (long long)rowsKept, outBytes, total, tParse, fR->UploadWaitSeconds(), fR->UploadSeconds(), tCut, tWrite,
                     (double)bytesIn / total / 1e9, kjson.c_str(), kms);
         return 0;
     } catch (const std::exception& e) {
