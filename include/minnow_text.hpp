@@ -96,13 +96,21 @@ class Reader {
         // mapped and go to the device straight from the page cache.  While block b is parsed (and the caller cuts, encodes and
         // writes it), block b + 1 is already on its way: a second thread with a library context of its own maps it and copies
         // it into the other of two device buffers (the reference's callers walk the blocks in order, text_to_minh.go:205).
+        const bool trace = std::getenv("MNW_TEXT_TRACE") != nullptr;
+        const auto tr0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (trace) std::fprintf(stderr, "Block(%d) %s at %.3f ms\n", b, what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count());
+        };
         std::unique_ptr<Upload> up = takeUpload(b);
+        lap("upload taken");
         if (b + 1 < Blocks() && blockSizes_[(size_t)b + 1] > 0) startUpload(b + 1);
+        lap("next upload started");
         const uint8_t* const text = up->block->data;
         const int64_t nbytes = blockSizes_[(size_t)b];
         int64_t lines = 0, rows = 0;
         if (up->dev) minnow::detail::check(mnw_text_rows_resident(ctx, text, up->dev, nbytes, config_.Separator, config_.Comment, &lines, &rows));
         else minnow::detail::check(mnw_text_rows(ctx, text, nbytes, config_.Separator, config_.Comment, &lines, &rows));
+        lap("rows counted");
         // splitByType, text.go:202-221
         std::vector<int32_t> fIdx, iIdx;
         std::vector<size_t> fAt, iAt;
@@ -138,6 +146,7 @@ class Reader {
                                                  fIdx.data() + f0, (int)nf, fo.data(), iIdx.data() + i0, (int)ni, io.data(), rows, &n));
             f0 += nf; i0 += ni;
         } while (f0 < fIdx.size() || i0 < iIdx.size());
+        lap("parsed");
         return out;
     }
 
@@ -156,10 +165,17 @@ class Reader {
         if (pending_ && pending_->b == b) up = std::move(pending_);
         pending_.reset();
         if (up && !up->err.empty()) throw Error(up->err);
-        if (!up) {                                       // first block, or blocks asked for out of order: no prefetch to use
-            up.reset(new Upload());
-            up->b = b;
-            up->block.reset(new Mapped(fileno(f_), blockStarts_[(size_t)b], blockSizes_[(size_t)b]));
+        if (!up) {                                       // first block, or blocks asked for out of order: fetch it now, the same way
+            startUpload(b);
+            joinUpload();
+            up = std::move(pending_);
+            pending_.reset();
+            if (up && !up->err.empty()) throw Error(up->err);
+            if (!up || !up->block) {
+                up.reset(new Upload());
+                up->b = b;
+                up->block.reset(new Mapped(fileno(f_), blockStarts_[(size_t)b], blockSizes_[(size_t)b]));
+            }
         }
         return up;
     }
@@ -217,7 +233,10 @@ class Reader {
             if (len <= 0) { static const uint8_t none = 0; data = &none; return; }
             const int64_t page = (int64_t)sysconf(_SC_PAGESIZE), a = offset / page * page;
             maplen = (size_t)(offset - a + len);
-            base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, (off_t)a);
+            // (not populated: the block's bytes reach the device by pread into pinned memory; the mapping is only looked at for the
+            // few literals the host has to convert itself.  Populating it cost 32k page-table entries per 128 MiB block on the way
+            // in and again on the way out: 2 ms of every Block call)
+            base = mmap(nullptr, maplen, PROT_READ, MAP_PRIVATE, fd, (off_t)a);
             if (base == MAP_FAILED) { base = nullptr; throw Error("mmap of the text block failed"); }
             data = static_cast<const uint8_t*>(base) + (offset - a);
         }
