@@ -7,6 +7,7 @@
 #include <fstream>
 #include <iostream>
 #include <iterator>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -183,6 +184,53 @@ static void TestLargeBlocks() {
     rd->Close();
 }
 
+// The reader's read-ahead (next block, same columns) must never change what a call returns: blocks asked for front to back (every
+// prefetch used), backwards, and with the column set changing between calls (every prefetch missed) give the floats and
+// ints of a reader that does not read ahead (same dither seed), value for value.
+static void TestReadAhead() {
+    const std::vector<Column> columns = {col(Int64), col(Float32), col(Int), col(Float, 0, 0, 250, 0.001f), col(Float, 1, 8, 16, 0.01f)};
+    Blocks blk;
+    uint64_t s = 1234567ull;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) / 9007199254740992.0; };
+    const int nblk = 7;
+    for (int k = 0; k < nblk; ++k) {
+        const size_t n = 30000 + 1111 * (size_t)k;
+        std::vector<int64_t> a(n), c(n); std::vector<float> b(n), d(n), e(n);
+        for (size_t i = 0; i < n; ++i) {
+            a[i] = (int64_t)(rnd() * 1e12); b[i] = (float)(rnd() * 100.0); c[i] = 500 + (int64_t)(rnd() * 90000);
+            d[i] = (float)(rnd() * 250.0); e[i] = (float)std::pow(10.0, 8.5 + 7.0 * rnd());
+        }
+        blk.i64.push_back(a); blk.f32.push_back(b); blk.in.push_back(c); blk.fl.push_back(d); blk.lg.push_back(e);
+    }
+    const std::string fn = scratch + "/ahead.minh";
+    writeFile(fn, columns, blk, true);
+    auto plain = Open(fn), ahead = Open(fn);
+    plain->ReadAhead = false; plain->DitherSeed = 77; ahead->DitherSeed = 77;
+    auto same = [&](int b, const std::vector<std::string>& in, const std::vector<std::string>& fn2) {
+        const size_t n = (size_t)plain->BlockLengths[(size_t)b];
+        std::vector<std::vector<int64_t>> i1(in.size(), std::vector<int64_t>(n)), i2 = i1;
+        std::vector<std::vector<float>> f1(fn2.size(), std::vector<float>(n)), f2 = f1;
+        std::map<std::string, int64_t*> p1, p2; std::map<std::string, float*> q1, q2;
+        for (size_t k = 0; k < in.size(); ++k) { p1[in[k]] = i1[k].data(); p2[in[k]] = i2[k].data(); }
+        for (size_t k = 0; k < fn2.size(); ++k) { q1[fn2[k]] = f1[k].data(); q2[fn2[k]] = f2[k].data(); }
+        if (!in.empty()) { plain->IntBlock(b, p1); ahead->IntBlock(b, p2); }
+        if (!fn2.empty()) { plain->FloatBlock(b, q1); ahead->FloatBlock(b, q2); }
+        bool ok = true;
+        for (size_t k = 0; k < in.size(); ++k) ok = ok && i1[k] == i2[k];
+        for (size_t k = 0; k < fn2.size(); ++k) ok = ok && std::memcmp(f1[k].data(), f2[k].data(), n * 4) == 0;
+        return ok;
+    };
+    for (int b = 0; b < nblk; ++b) EXPECT(same(b, {"int64", "int"}, {"float32", "float", "log"}), "front to back, block " << b);
+    for (int b = nblk - 1; b >= 0; --b) EXPECT(same(b, {"int64", "int"}, {"float", "log"}), "backwards, block " << b);
+    for (int b = 0; b < nblk; ++b) {
+        const bool odd = b & 1;
+        EXPECT(same(b, odd ? std::vector<std::string>{"int"} : std::vector<std::string>{"int64", "int"},
+                    odd ? std::vector<std::string>{"log"} : std::vector<std::string>{"float", "float32"}), "changing columns, block " << b);
+    }
+    EXPECT(same(3, {}, {"log"}) && same(4, {}, {"log"}) && same(4, {"int"}, {}), "single kinds");
+    plain->Close(); ahead->Close();
+}
+
 // a NaN survives processFloatGroup (both comparisons are false), quantizes to MinInt64 on amd64 and makes the block 64 bits wide:
 // the writer must then take its wide stream slots, from host and from device arrays alike
 static void TestNaNBlock() {
@@ -243,6 +291,7 @@ int main(int argc, char** argv) {
         TestReaderWriter();
         TestGoldenFile();
         TestLargeBlocks();
+        TestReadAhead();
         TestNaNBlock();
         TestPanics();
     } catch (const std::exception& e) {
@@ -250,6 +299,6 @@ int main(int argc, char** argv) {
         return 1;
     }
     if (failures) { std::cerr << failures << " failure(s)\n"; return 1; }
-    std::cout << "ok: 5 minh host tests\n";
+    std::cout << "ok: 6 minh host tests\n";
     return 0;
 }

@@ -80,7 +80,7 @@ def test_cpp_minh_host_tests_on_gpu(tmp_path):
     scratch.mkdir()
     r = subprocess.run([exe, str(scratch), str(gold)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ok: 5 minh host tests" in r.stdout
+    assert "ok: 6 minh host tests" in r.stdout
 
 
 @pytest.mark.gpu
