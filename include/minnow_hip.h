@@ -344,6 +344,7 @@ const char *mnw_kernel_name(int kernel_id);
 #define MNW_C_EXACT_BLOCKS        3  /* float blocks sent to the exact sequential path (out-of-domain data) */
 #define MNW_C_FUSED_BATCHES       4  /* float batches encoded by the opt-in fused launch k_encode_f32 */
 #define MNW_C_INT_SINGLE_READ_BATCHES 5 /* batches whose int64 blocks were encoded by k_encode_reg_i64 (aborts count in MNW_C_SINGLE_READ_ABORTS) */
+#define MNW_C_BACKOFF_BATCHES      7  /* batches that skipped the single-read kernels because a recent attempt had given up (single_read_backoff) */
 #define MNW_C_VEC3_SINGLE_READ_CALLS 6 /* mnw_vectors_encode calls that went through k_encode_reg_vec3 (aborts as above) */
 #define MNW_C_COUNT               8
 int mnw_counters_get(mnw_ctx *ctx, int64_t out[MNW_C_COUNT]);
@@ -360,6 +361,9 @@ int mnw_counters_reset(mnw_ctx *ctx);
  * big_blocks: 1 (default) = that includes blocks of more than 2^22 elements; 0 = those take reduce + pack.
  * reg_weighted: 1 (default) = the single-read kernel hands its work out in weighted rounds (the workgroups that the
  *        hardware schedules first get 14 items where the last get 10); 0 = every workgroup the same share.
+ * single_read_backoff: 1 (default) = after a single-read launch has given up (something else holds part of the GPU), the next batch
+ *        goes to the two-launch path without trying; a give-up right after the pause doubles it (1, 2, 4 ... 64 batches), a
+ *        launch that runs to its end resets it.  0 = try every time (50 ms per give-up).
  * reg_round_table: which built-in table of round sizes the weighted hand-out uses (0, default: the quarters of the grid take
  *        14 / 12 / 11 / 10 items per cycle; 1..4: other ratios, kept for measurements -- none was faster).
  * reg_test_drop_item: test hook (default -1): the single-read kernel never publishes the statistics of that item, so

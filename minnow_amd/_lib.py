@@ -12,7 +12,7 @@ STATUS_NAMES = {
 }
 K_COUNT = 21
 C_COUNT = 8
-COUNTER_NAMES = ("single_read_batches", "single_read_aborts", "two_pass_batches", "exact_blocks", "fused_batches", "int_single_read_batches", "vec3_single_read_calls")
+COUNTER_NAMES = ("single_read_batches", "single_read_aborts", "two_pass_batches", "exact_blocks", "fused_batches", "int_single_read_batches", "vec3_single_read_calls", "backoff_batches")
 
 
 class MnwError(RuntimeError):

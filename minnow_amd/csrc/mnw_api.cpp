@@ -282,6 +282,8 @@ struct mnw_ctx {
     int reg_blocks_per_cu = 0;
     int reg_xf_blocks_per_cu = 0;  // ... of its instantiation with the minh value transform   // co-resident workgroups of k_encode_reg_f32 per CU (occupancy query)
     int reg_vec3_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_vec3 per CU
+    int single_read_backoff = 1; // after a give-up, the next batches skip the single-read kernels (1, 2, 4, ... 64 batches on consecutive give-ups)
+    int sr_backoff = 0, sr_backoff_left = 0;
     int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
     int vec3_single_read = 0;    // minp vectors: 1 = the grid is read once (k_encode_reg_vec3) when the geometry allows.  Opt-in: measured
@@ -1169,6 +1171,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "single_read_int")) { c->single_read_int = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_single_read")) { c->vec3_single_read = value != 0; return MNW_OK; }
     if (!strcmp(name, "unlog_fused")) { c->unlog_fused = value != 0; return MNW_OK; }
+    if (!strcmp(name, "single_read_backoff")) { c->single_read_backoff = value != 0; c->sr_backoff = c->sr_backoff_left = 0; return MNW_OK; }
     if (!strcmp(name, "reg_round_table")) { if (value < 0 || value > 4) return fail(c, MNW_E_ARG, "reg_round_table: 0..4"); c->reg_round_table = (int)value; return MNW_OK; }
     if (!strcmp(name, "big_blocks")) { c->big_blocks = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_tiles_per_wg")) { c->vec3_tiles_per_wg = (int)value; return MNW_OK; }
@@ -1304,7 +1307,14 @@ int mnw_encode_blocks_async(mnw_ctx* c, mnw_stream_t stream, const mnw_enc_job* 
         c->pend_int_reg = false;
         c->pend_nslot = nslot;
         bool did_f = false, did_i = false;
-        if (!fused && ((c->single_read && nfloat > 0) || (c->single_read_int && nslot > nfloat))) {
+        // Something else is running on this GPU if the last attempt gave up: do not pay its 50 ms bound again at once
+        bool backing_off = false;
+        if (!fused && c->single_read_backoff && c->sr_backoff_left > 0 && ((c->single_read && nfloat > 0) || (c->single_read_int && nslot > nfloat))) {
+            --c->sr_backoff_left;
+            c->counters[MNW_C_BACKOFF_BATCHES]++;
+            backing_off = true;
+        }
+        if (!fused && !backing_off && ((c->single_read && nfloat > 0) || (c->single_read_int && nslot > nfloat))) {
             // keep the group-relative numbering of what turns out not to be eligible
             std::vector<int64_t> keep(nslot);
             for (int k = 0; k < nslot; ++k) keep[k] = sl->h_jobs[k].tile0;
@@ -1361,6 +1371,8 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
         // The persistent launch gave up (its workgroups were not all co-resident, e.g. another kernel held
         // part of the GPU): rerun its jobs through the two-kernel path.  Still the GPU path.
         c->counters[MNW_C_SINGLE_READ_ABORTS]++;
+        c->sr_backoff = c->sr_backoff ? (c->sr_backoff < 64 ? 2 * c->sr_backoff : 64) : 1;
+        c->sr_backoff_left = c->sr_backoff;
         sl->shadow_tag = 0;                       // the abort word on the device is set: the next batch must prepare
         for (int pass = 0; pass < 2; ++pass) {    // group-relative tile numbering again
             if (!(pass == 0 ? f_reg : i_reg)) continue;
@@ -1386,6 +1398,8 @@ int mnw_encode_blocks_finish(mnw_ctx* c, mnw_stream_t stream, mnw_block_meta* me
         if (i_reg) rc = launch_encode_range(c, sl, s, c->pend_nfloat, c->pend_nslot, MNW_INT_GROUP);
         if (rc) return rc;
         HIPCHK(c, hipStreamSynchronize(s));
+    } else if (f_reg || i_reg) {
+        c->sr_backoff = 0;                        // a single-read launch ran to its end: nothing in the way any more
     }
     std::vector<Meta> res(njobs);
     for (int i = 0; i < njobs; ++i) res[i] = c->pend_slot[i] >= 0 ? sl->h_meta[c->pend_slot[i]] : c->pend_host[i];
@@ -1601,7 +1615,13 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
         const int64_t vt = mnw::vec3_tiles(n_file, sub_cells);
         // ---- the grid read once (k_encode_reg_vec3): every block at most G vtiles for a resident grid of G workgroups ----
         bool two_pass = true;
-        if (c->vec3_single_read) {
+        bool v3_backing_off = false;
+        if (c->vec3_single_read && c->single_read_backoff && c->sr_backoff_left > 0) {
+            --c->sr_backoff_left;
+            c->counters[MNW_C_BACKOFF_BATCHES]++;
+            v3_backing_off = true;
+        }
+        if (c->vec3_single_read && !v3_backing_off) {
             if (c->reg_vec3_blocks_per_cu == 0) {
                 const int occ = mnw::encode_reg_vec3_blocks_per_cu();
                 c->reg_vec3_blocks_per_cu = occ < 1 ? -1 : (occ > 3 ? 3 : occ);
@@ -1630,9 +1650,12 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
                 HIPCHK(c, wait_stream(s));
                 c->counters[MNW_C_VEC3_SINGLE_READ_CALLS]++;
                 two_pass = false;
+                if (sl->h_sync[0] == 0) c->sr_backoff = 0;
                 if (sl->h_sync[0] != 0) {
                     // gave up (something else held part of the GPU): the two launches below redo the call
                     c->counters[MNW_C_SINGLE_READ_ABORTS]++;
+                    c->sr_backoff = c->sr_backoff ? (c->sr_backoff < 64 ? 2 * c->sr_backoff : 64) : 1;
+                    c->sr_backoff_left = c->sr_backoff;
                     rc = prepare_slot(c, sl, s, (int)(3 * s3), true);
                     if (rc) return rc;
                     two_pass = true;

@@ -354,6 +354,7 @@ def test_vectors_single_read_shapes_and_give_up(mnw, oracle, torch_mod, nf, sub_
 
     with mnw.Context(0) as c:
         c.set_option("vec3_single_read", 1)
+        c.set_option("single_read_backoff", 0)    # (every call is to try the single-read kernel)
         c.timing_enable(True)
         for rep in range(3):                      # (generations: the records of an earlier call must not satisfy a later one)
             packed.zero_()

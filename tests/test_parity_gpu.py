@@ -526,6 +526,7 @@ def test_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
         jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, low, high, pixels, 1)
                 for t, o in zip(ts, outs)]
         torch.cuda.synchronize()
+        c2.set_option("single_read_backoff", 0)           # (this test wants every batch to try the single-read kernel)
         c2.set_option("reg_test_drop_item", 300)          # an item of the third block
         c2.timing_enable(True)
         t0 = time.perf_counter()
@@ -658,6 +659,7 @@ def test_int_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
         jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.INT_GROUP) for t, o in zip(ts, outs)]
         jobs.append(mnw.EncJob(ft.data_ptr(), fo.data_ptr(), ft.numel(), fo.numel(), mnw.FLOAT_GROUP, 0.0, 250.0, 250000, 1))
         torch.cuda.synchronize()
+        c2.set_option("single_read_backoff", 0)           # (this test wants every batch to try the single-read kernel)
         c2.set_option("reg_test_drop_item", 300)          # an item of the second int block; beyond the float block's 128 items
         c2.timing_enable(True)
         metas = c2.encode_blocks(jobs)
@@ -757,6 +759,7 @@ def test_single_read_large_block_abort_and_fallback(mnw, oracle, torch_mod):
     rng = np.random.default_rng(27)
     xs = [np.mod(125 + 20 * rng.standard_normal(2**24), 250.0).astype(np.float32)]
     with mnw.Context(0) as c2:
+        c2.set_option("single_read_backoff", 0)           # (this test wants every batch to try the single-read kernel)
         c2.set_option("reg_test_drop_item", 1500)
         c2.timing_enable(True)
         _encode_and_compare(mnw, oracle, torch_mod, c2, xs)
@@ -1219,3 +1222,57 @@ def test_copy_file_to_device(mnw, ctx, torch_mod, tmp_path):
         assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev.data_ptr()), fd, 1, A([44_999_000]), A([5000]), None) != 0
     finally:
         os.close(fd)
+
+
+def test_single_read_backs_off_after_a_give_up(mnw, oracle, torch_mod):
+    """A launch that gave up says something else holds part of the GPU: the next batch must not pay the 50 ms bound again
+    but go to the two-launch path at once; a give-up right after the pause doubles it; a launch that runs to its end resets
+    it.  Same bytes all along."""
+    import time
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    xs = [np.mod(125 + 20 * rng.standard_normal(2**19), 250.0).astype(np.float32) for _ in range(3)]
+    want = [oracle.float_encode(x, 0.0, 250.0, 250000, True, literal=False) for x in xs]
+    with mnw.Context(0) as c2:
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(4 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.FLOAT_GROUP, 0.0, 250.0, 250000, 1) for t, o in zip(ts, outs)]
+        torch.cuda.synchronize()
+
+        def run():
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            metas = c2.encode_blocks(jobs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            for m, o, (omin, obits, odata) in zip(metas, outs, want):
+                assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
+                assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
+            return dt
+
+        run()
+        assert c2.counters()["single_read_batches"] == 1
+        c2.set_option("reg_test_drop_item", 70)
+        assert run() > 0.04                                   # gives up after its bounded wait
+        cnt = c2.counters()
+        assert (cnt["single_read_aborts"], cnt["backoff_batches"]) == (1, 0)
+        assert run() < 0.03                                   # one batch of pause: no attempt, no wait
+        cnt = c2.counters()
+        assert (cnt["single_read_aborts"], cnt["backoff_batches"], cnt["single_read_batches"]) == (1, 1, 2)
+        assert run() > 0.04                                   # tries again, gives up again: the pause doubles
+        assert c2.counters()["single_read_aborts"] == 2
+        assert run() < 0.03 and run() < 0.03
+        assert c2.counters()["backoff_batches"] == 3
+        c2.set_option("reg_test_drop_item", -1)               # the co-tenant has gone
+        assert run() < 0.03
+        cnt = c2.counters()
+        assert (cnt["single_read_aborts"], cnt["backoff_batches"], cnt["single_read_batches"]) == (2, 3, 4)
+        c2.set_option("reg_test_drop_item", 70)               # and the next give-up starts from a pause of one again
+        run(); run()
+        c2.set_option("reg_test_drop_item", -1)
+        run()
+        cnt = c2.counters()
+        assert (cnt["single_read_aborts"], cnt["backoff_batches"], cnt["single_read_batches"]) == (3, 4, 6)
