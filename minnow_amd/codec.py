@@ -234,6 +234,15 @@ class Context:
         arr = (MinhColC * max(len(cols), 1))(*[MinhColC(None, d, n, 0.0, 0.0, 1, 0) for d, n in cols])
         self._check(self._L.mnw_minh_unlog(self._h, stream, arr, len(cols)))
 
+    # -- a reader's f.Read per block (go/reader.go:121-126), for many blocks at once ---------------------
+    def copy_file_to_device(self, dev_ptr, fd, file_offsets, nbytes, dst_offsets=None):
+        """Byte ranges of the open file `fd` into the device buffer at dev_ptr: packed back to back in the order given, or range i at
+        dev_ptr + dst_offsets[i]."""
+        n = len(file_offsets)
+        A = lambda v: (C.c_int64 * max(n, 1))(*[int(x) for x in v])
+        self._check(self._L.mnw_copy_file_to_device(self._h, C.c_void_p(int(dev_ptr)), int(fd), n, A(file_offsets), A(nbytes),
+                                                    A(dst_offsets) if dst_offsets is not None else None))
+
     # -- text catalogue ingest (go/text) ------------------------------------------------------------
     def text_parse(self, data, sep, comment, float_cols, float_out_ptrs, int_cols, int_out_ptrs, capacity_rows):
         """data: bytes-like host text; *_out_ptrs: device pointers of capacity_rows elements each -> rows kept"""

@@ -1199,10 +1199,9 @@ def test_copy_file_to_device(mnw, ctx, torch_mod, tmp_path):
     try:
         offs = [0, 17, 1_000_003, 20_000_000, 44_999_990, 5]
         lens = [1, 4_000_001, 0, 24_999_990, 11, 19_000_000]
-        A = lambda v: (C.c_int64 * len(v))(*v)
         dev = torch.zeros(sum(lens) + 64, dtype=torch.uint8, device="cuda:0")
         torch.cuda.synchronize()
-        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev.data_ptr()), fd, len(offs), A(offs), A(lens), None) == 0
+        ctx.copy_file_to_device(dev.data_ptr(), fd, offs, lens)
         want = np.concatenate([data[o:o + n] for o, n in zip(offs, lens)])
         got = dev.cpu().numpy()
         assert np.array_equal(got[: want.size], want) and not got[want.size:].any()
@@ -1212,14 +1211,15 @@ def test_copy_file_to_device(mnw, ctx, torch_mod, tmp_path):
             doff.append(at); at += n + 37
         dev2 = torch.full((at + 64,), 255, dtype=torch.uint8, device="cuda:0")
         torch.cuda.synchronize()
-        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev2.data_ptr()), fd, len(offs), A(offs), A(lens), A(doff)) == 0
+        ctx.copy_file_to_device(dev2.data_ptr(), fd, offs, lens, doff)
         got = dev2.cpu().numpy()
         ref = np.full(at + 64, 255, dtype=np.uint8)
         for o, n, d in zip(offs, lens, doff):
             ref[d:d + n] = data[o:o + n]
         assert np.array_equal(got, ref)
         # past the end of the file: an error, not a short copy
-        assert ctx._L.mnw_copy_file_to_device(ctx.handle, C.c_void_p(dev.data_ptr()), fd, 1, A([44_999_000]), A([5000]), None) != 0
+        with pytest.raises(mnw.MnwError):
+            ctx.copy_file_to_device(dev.data_ptr(), fd, [44_999_000], [5000])
     finally:
         os.close(fd)
 
