@@ -538,7 +538,17 @@ def main():
         if not a.no_minp:
             del y
             torch.cuda.empty_cache()
+            if dist is not None:
+                dist.barrier()                           # the ranks run their cells side by side
             extra["minp_cell"] = minp_leg(mnw, ctx, device, 5, timing)
+            if dist is not None:
+                # configs[3] as the reference runs it: one file cell per GPU (go/minp/minp.go:98-118), no exchange between them.
+                # All ranks ran their cell at the same time: the snapshot's rate = all particles / the slowest rank's step.
+                slowest = shard.max_over_ranks(extra["minp_cell"]["ms_per_step"] * 1e-3, device=cdev)
+                extra["minp_cell"]["all_ranks"] = {"cells": world, "particles": world * extra["minp_cell"]["particles"],
+                                                   "slowest_rank_ms_per_step": slowest * 1e3,
+                                                   "value": 12.0 * world * extra["minp_cell"]["particles"] / slowest / 1e9,
+                                                   "unit": "GB/s of input (12 B per particle), encode + decode, all ranks"}
             torch.cuda.empty_cache()
             extra["catalogue_c3"] = catalogue_leg(mnw, ctx, device, 10 ** 8, 3, timing)
     counters = ctx.counters()
