@@ -1290,6 +1290,12 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     const int tid = threadIdx.x;
     MNW_STAMP_DECL
     MNW_STAMP_START
+#ifdef MNW_DIAG_SETPRIO       // diagnostic builds only: issue priority against the hardware's preference for a CU's oldest waves
+    { const int q = (int)(blockIdx.x * 4u / gridDim.x);
+      if (MNW_DIAG_SETPRIO == 1) { if (q == 1) __builtin_amdgcn_s_setprio(1); else if (q == 2) __builtin_amdgcn_s_setprio(2); else if (q == 3) __builtin_amdgcn_s_setprio(3); }
+      if (MNW_DIAG_SETPRIO == 2) { if (q == 3) __builtin_amdgcn_s_setprio(1); }
+      if (MNW_DIAG_SETPRIO == 3) { if (q >= 2) __builtin_amdgcn_s_setprio(1); } }
+#endif
 
     // the item in e[] (all wave-uniform)
     u32x4 e[kV];
