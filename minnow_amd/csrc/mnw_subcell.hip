@@ -978,7 +978,11 @@ __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restri
                     MNW_GLOBAL_SC sc_f32x4* p = (MNW_GLOBAL_SC sc_f32x4*)(vec_out + 3 * (int64_t)i);
                     const sc_f32x4 q0 = {o[0].x, o[1].x, o[2].x, o[0].y}, q1 = {o[1].y, o[2].y, o[0].z, o[1].z},
                                    q2 = {o[2].z, o[0].w, o[1].w, o[2].w};
+#ifdef MNW_DIAG_NT_STORES      // diagnostic builds only: streaming stores for the grid
+                    __builtin_nontemporal_store(q0, p); __builtin_nontemporal_store(q1, p + 1); __builtin_nontemporal_store(q2, p + 2);
+#else
                     p[0] = q0; p[1] = q1; p[2] = q2;
+#endif
                 }
             }
             lds_barrier();
