@@ -78,4 +78,22 @@ te, _ = best(enci)
 td, _ = best(deci)
 assert np.array_equal(xi, yi)
 res["int64_5e7"] = {"encode_s": te, "decode_s": td, "encode_GBps_input": 8.0 * m / te / 1e9, "decode_GBps_output": 8.0 * m / td / 1e9, "bits": bits.value}
+# BASELINE configs[0]: one int64 block of 1e6 elements, x = 1000 + U{0..2^b-1} -- what one Writer.Data call costs
+m1 = 10 ** 6
+for b1 in (11, 21):
+    x1 = (1000 + rng.integers(0, 2 ** b1, size=m1, dtype=np.int64))
+    y1 = np.empty_like(x1)
+    o1 = np.empty(8 * m1 + 64, dtype=np.uint8)
+
+    def enc1():
+        assert L.mnw_int_encode(h, ptr(x1), m1, C.byref(mn), C.byref(bits), ptr(o1), o1.size, C.byref(olen)) == 0
+
+    def dec1():
+        assert L.mnw_int_decode(h, ptr(o1), olen.value, mn.value, bits.value, m1, ptr(y1)) == 0
+
+    te, _ = best(enc1)
+    td, _ = best(dec1)
+    assert np.array_equal(x1, y1)
+    res["int64_1e6_b%d" % b1] = {"encode_us": te * 1e6, "decode_us": td * 1e6, "encode_GBps_input": 8.0 * m1 / te / 1e9,
+                                 "decode_GBps_output": 8.0 * m1 / td / 1e9, "bits": bits.value}
 print(json.dumps(res))
