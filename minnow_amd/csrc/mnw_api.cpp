@@ -449,6 +449,15 @@ void stager_free(mnw_ctx* c) {
 
 // Host (pageable) -> device, enqueued on s.  When it returns every byte has left the caller's buffer (it sits in device
 // memory or in a pinned buffer whose DMA is queued on s): nothing of `src` is retained.
+// the piece a staged transfer moves at a time: a whole pinned buffer, or -- so that a transfer of less than a few buffers still
+// overlaps its host copy with its DMA -- a quarter of the transfer (1 MiB at least)
+static size_t stage_step(const Stager& g, size_t bytes) {
+    if (bytes >= 4 * g.chunk) return g.chunk;
+    size_t st = ((bytes + 3) / 4 + 4095) & ~(size_t)4095;
+    if (st < (1u << 20)) st = 1u << 20;
+    return st < g.chunk ? st : g.chunk;
+}
+
 int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t bytes) {
     if (bytes == 0) return MNW_OK;
     if ((int64_t)bytes < c->stage_min) {
@@ -459,8 +468,9 @@ int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t b
     int rc = stager_init(c);
     if (rc) return rc;
     Stager& g = c->stg;
-    for (size_t off = 0; off < bytes; off += g.chunk) {
-        const size_t len = bytes - off < g.chunk ? bytes - off : g.chunk;
+    const size_t step = stage_step(g, bytes);
+    for (size_t off = 0; off < bytes; off += step) {
+        const size_t len = bytes - off < step ? bytes - off : step;
         const int b = g.next; g.next = (g.next + 1) % Stager::kBufs;
         if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
         g.pool->copy(g.pin[b], (const uint8_t*)src + off, len);
@@ -590,9 +600,10 @@ int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t b
     Stager& g = c->stg;
     for (int b = 0; b < Stager::kBufs; ++b)
         if (g.busy[b]) { HIPCHK(c, hipEventSynchronize(g.ev[b])); g.busy[b] = false; }
-    const size_t nchunks = (bytes + g.chunk - 1) / g.chunk;
+    const size_t step = stage_step(g, bytes);
+    const size_t nchunks = (bytes + step - 1) / step;
     auto issue = [&](size_t k) -> hipError_t {
-        const size_t off = k * g.chunk, len = bytes - off < g.chunk ? bytes - off : g.chunk;
+        const size_t off = k * step, len = bytes - off < step ? bytes - off : step;
         const int b = (int)(k % Stager::kBufs);
         hipError_t e = hipMemcpyAsync(g.pin[b], (const uint8_t*)dev_src + off, len, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipEventRecord(g.ev[b], s);
@@ -600,7 +611,7 @@ int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t b
     };
     for (size_t k = 0; k < nchunks && k < (size_t)Stager::kBufs; ++k) HIPCHK(c, issue(k));
     for (size_t k = 0; k < nchunks; ++k) {
-        const size_t off = k * g.chunk, len = bytes - off < g.chunk ? bytes - off : g.chunk;
+        const size_t off = k * step, len = bytes - off < step ? bytes - off : step;
         const int b = (int)(k % Stager::kBufs);
         HIPCHK(c, hipEventSynchronize(g.ev[b]));
         g.pool->copy((uint8_t*)dst + off, g.pin[b], len);
