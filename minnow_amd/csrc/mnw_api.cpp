@@ -525,16 +525,17 @@ int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const
         fill = 0; cur.clear();
         return MNW_OK;
     };
+    const size_t step = stage_step(g, total);
     size_t packed = 0;
     for (int i = 0; i < n; ++i) {
         const size_t d0 = dst_off ? (size_t)dst_off[i] : packed;
         size_t off = 0;
         while (off < (size_t)len[i]) {
-            size_t take = std::min((size_t)len[i] - off, g.chunk - fill);
+            size_t take = std::min((size_t)len[i] - off, step - fill);
             if (take > kSub) take = kSub;
             cur.push_back(Piece{file_off[i] + (int64_t)off, take, fill, d0 + off});
             off += take; fill += take;
-            if (fill == g.chunk) { rc = flush(); if (rc) return rc; }
+            if (fill == step) { rc = flush(); if (rc) return rc; }
         }
         packed += (size_t)len[i];
     }
@@ -555,15 +556,16 @@ int copy_d2h_batch(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const voi
     struct Piece { int item; size_t off, len, at; };
     std::vector<std::vector<Piece>> chunks;                  // the pieces of every pinned chunk
     {
+        const size_t step = stage_step(g, total);
         std::vector<Piece> cur;
         size_t fill = 0;
         for (int i = 0; i < n; ++i) {
             size_t off = 0;
             while (off < (size_t)len[i]) {
-                const size_t take = std::min((size_t)len[i] - off, g.chunk - fill);
+                const size_t take = std::min((size_t)len[i] - off, step - fill);
                 cur.push_back(Piece{i, off, take, fill});
                 off += take; fill += take;
-                if (fill == g.chunk) { chunks.push_back(cur); cur.clear(); fill = 0; }
+                if (fill == step) { chunks.push_back(cur); cur.clear(); fill = 0; }
             }
         }
         if (!cur.empty()) chunks.push_back(cur);
