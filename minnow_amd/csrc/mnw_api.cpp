@@ -56,7 +56,8 @@ int64_t vec3_reg_max_tiles_per_block();
 bool vec3_reg_geometry_ok(int64_t, int64_t);
 int encode_reg_vec3_blocks_per_cu();
 void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t);
-void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float);
+void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float, int, bool, int);
+bool vec3_unpack_geometry_ok(int64_t, int64_t);
 constexpr int kMinhBatch = 64;
 struct MinhCol { const float* src; float* dst; int64_t n; float low, high, high_below; int32_t xform; };
 struct MinhArgs { MinhCol col[kMinhBatch]; };
@@ -286,6 +287,8 @@ struct mnw_ctx {
     int sr_backoff = 0, sr_backoff_left = 0;
     int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
+    int vec3_x_order = 1;        // minp vector kernels: workgroups in dispatch order take the sub-cells of one x-row together
+    int vec3_unpack_db = 1;      // k_unpack_vec3: two LDS word buffers and one barrier per vtile (0: one buffer, two barriers, more workgroups per CU)
     int vec3_single_read = 0;    // minp vectors: 1 = the grid is read once (k_encode_reg_vec3) when the geometry allows.  Opt-in: measured
                                  // no faster than k_reduce_vec3 + k_pack_vec3 on C4, and it needs its whole grid co-resident
     int reg_i64_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_i64 per CU
@@ -1191,6 +1194,8 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
     if (!strcmp(name, "stage_min_bytes")) { c->stage_min = value; return MNW_OK; }
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_x_order")) { c->vec3_x_order = value != 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_unpack_db")) { c->vec3_unpack_db = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_weighted")) { c->reg_weighted = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_test_drop_item")) { c->reg_drop_item = value; return MNW_OK; }
     if (!strcmp(name, "grid_cap")) { c->grid_cap = (int)value; return MNW_OK; }
@@ -1730,13 +1735,16 @@ int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int6
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     // ---- without staging: k_unpack_vec3 writes the grid itself --------------------------------------------
     bool fused = c->vec3_fused && !c->pending && (n_file / sub_cells) % 4 == 0 && n_file % 4 == 0 && ((uintptr_t)vec_out & 15) == 0 &&
-                 3 * s3 < (1 << 20);
+                 3 * s3 < (1 << 20) && mnw::vec3_unpack_geometry_ok(n_file, sub_cells);
+    int max_bits = 0;
     for (int64_t b = 0; b < 3 * s3 && fused; ++b) {
         const int k = (int)(b / s3);
         const mnw_block_meta& m = meta[b];
+        if (m.bits > max_bits) max_bits = (int)m.bits;
         if (m.bits < 0 || m.bits > 64) return fail(c, MNW_E_ARG, "decode: bits outside 0..64");
         if (m.bits > 0 && m.nbytes < mnw::array_bytes(m.bits, nsub3)) return fail(c, MNW_E_BUFLEN, "decode: stream shorter than ArrayBytes(bits, n)");
-        fused = m.bits <= 32 && pixels[k] > 0 && pixels[k] <= 0x7fffffffll && m.min >= -0x80000000ll &&
+        // (a negative minimum -- a block the exact path made of out-of-range data -- needs bound() as written: staging path)
+        fused = m.bits <= 32 && pixels[k] > 0 && pixels[k] <= 0x7fffffffll && m.min >= 0 &&
                 m.min + (int64_t)((1ull << m.bits) - 1) <= 0x7fffffffll;
     }
     if (fused) {
@@ -1764,7 +1772,8 @@ int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int6
         const int64_t vt = mnw::vec3_tiles(n_file, sub_cells);
         int64_t gl = c->vec3_tiles_per_wg > 0 ? (vt + c->vec3_tiles_per_wg - 1) / c->vec3_tiles_per_wg : (int64_t)c->cus * 8;
         int g = (int)(gl > vt ? vt : gl);
-        { ScopedTimer t(c, s, MNW_K_UNPACK_VEC3); mnw::launch_unpack_vec3(s, g, vec_out, n_file, sub_cells, sl->d_jobs, periodic != 0, L); }
+        { ScopedTimer t(c, s, MNW_K_UNPACK_VEC3); mnw::launch_unpack_vec3(s, g, vec_out, n_file, sub_cells, sl->d_jobs, periodic != 0, L, max_bits, c->vec3_unpack_db != 0,
+                                                                                   c->vec3_x_order && c->vec3_tiles_per_wg > 0 ? c->vec3_tiles_per_wg : 0); }
         HIPCHK(c, hipGetLastError());
         return release_slot(c, sl, s);
     }

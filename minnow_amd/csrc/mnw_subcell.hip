@@ -902,90 +902,224 @@ __global__ __launch_bounds__(256, 3) void k_encode_reg_vec3(Vec3RegArgs ra, cons
 // setSubCell).  32-bit streams only (bits <= 32, ring and minimum in int32: the NARROW class of
 // k_unpack_f32); anything else goes through the staging path.  HBM traffic: the streams + 12 B/particle
 // written, against streams + 12 B written + 12 B read + 12 B written of the staging path.
+//
+// Round 3: written against the instruction costs measured on gfx950 (tools/microbench/valu_cost.hip: add / sub / mul / fma
+// of float32, and / or / xor, add / sub of integers and right shifts issue every 2 cycles per SIMD; compares, selects, min / max,
+// left shifts, bit-field and funnel operations, conversions, integer multiplies and all float64 arithmetic every 4).  What a
+// sub-cell's block makes unnecessary is decided once per (sub-cell, component) in scalar code, not per element:
+//   * bound(buf, 0, pixels) (group.go:303): nothing when min + 2^bits - 1 < pixels, one unsigned minimum when min >= 0;
+//   * the reader's fix-up (minp.go:188-196): nothing when the block's largest / smallest possible value is inside [0, L) --
+//     every step of the dequantization is monotone in q + u, so the extremes of x are x of the extreme (q, u);
+//   * element c of a lane's group of four sits at bit (group start) + c b: one add, the dword address, one ds_read2_b32,
+//     one v_alignbit_b32 (which takes the shift from the low five bits itself) and the mask.
+// float32(float64(q) + u) is one float64 fma (u = z 2^-32 is an exact product, so the fused form rounds once, like the
+// addition) between three conversions.  The stream words are double buffered in LDS (one barrier per vtile), sized by the
+// widest block of the call: 26 KB per workgroup for C4's 17 bits, six workgroups per CU.
 // ------------------------------------------------------------------------------------------------
+struct V3Dec {                  // one component's block of the current sub-cell; wave-uniform
+    uint32_t b, mask;
+    uint32_t mn, wrap;          // minimum (>= 0 on this path); pixels if bound() can fire, else 0 (then min(q, q - 0) = q)
+    uint32_t ka, kb, sh;        // dither key halves; bit offset of the stream inside its first staged word
+    float low, dx;
+    bool fix_lo, fix_hi;        // the periodic fix-up can fire below 0 / at or above L
+};
+
+__device__ __forceinline__ V3Dec v3dec_make(const DevJob& jb, int periodic, float L) {
+    V3Dec d;
+    d.b = (uint32_t)jb.bits;
+    d.mask = d.b == 0 ? 0u : (d.b == 32 ? ~0u : ((1u << d.b) - 1u));
+    d.mn = (uint32_t)jb.min;
+    d.low = jb.low; d.dx = jb.dxq;
+    const uint64_t key = dither_key(jb.seed, jb.block, 0);       // element indices stay below 2^32
+    d.ka = (uint32_t)key; d.kb = (uint32_t)(key >> 32);
+    d.sh = (uint32_t)((uintptr_t)jb.src & 7) * 8;
+    const int64_t top = jb.min + (int64_t)d.mask;                // largest value the stream can hold (host: min >= 0, top fits int32)
+    const bool wraps = top >= jb.pixels;
+    d.wrap = wraps ? (uint32_t)jb.pixels : 0u;
+    // extremes of the dequantized value over everything the block can hold: q + u is in [qmin, qmax + 1 - 2^-32] and
+    // x = fl(fl(dx * fl32(q + u)) + low) is monotone non-decreasing in it for dx >= 0
+    d.fix_lo = d.fix_hi = periodic != 0;
+    if (periodic && d.dx >= 0.0f) {
+        const int64_t qmax = wraps ? jb.pixels - 1 : top, qmin = wraps ? 0 : jb.min;
+        const float xmax = __fadd_rn(__fmul_rn(d.dx, (float)__fma_rn((double)0xffffffffu, 0x1p-32, (double)qmax)), d.low);
+        const float xmin = __fadd_rn(__fmul_rn(d.dx, (float)(double)qmin), d.low);
+        d.fix_hi = !(xmax < L);
+        d.fix_lo = !(xmin >= 0.0f);
+    }
+    return d;
+}
+
+// element at bit `pos` of the staged words
+__device__ __forceinline__ uint32_t v3_extract(const uint32_t* __restrict__ l32, uint32_t pos, uint32_t mask) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(l32) + ((pos >> 3) & ~3u));
+    return __builtin_amdgcn_alignbit(p[1], p[0], pos) & mask;
+}
+
+// four consecutive elements of one component, starting at bit pos0 of the staged words and at element j of the block -> floats
+__device__ __forceinline__ sc_f32x4 v3_dequant4(const V3Dec& d, const uint32_t* __restrict__ l32, uint32_t pos0, uint32_t j, float L) {
+    sc_f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        // group.go:262, then bound(buf, 0, pixels) with q >= 0: one wrap from above, as an unsigned minimum
+        uint32_t q = d.mn + v3_extract(l32, pos0 + (uint32_t)c * d.b, d.mask);
+        q = min(q, q - d.wrap);
+#ifdef MNW_DIAG_NO_DITHER       // diagnostic builds only: price the dither and the float64 detour
+        const float f = (float)(int32_t)q;
+#else
+        const uint32_t z = dither_bits(j + (uint32_t)c, d.ka, d.kb);
+        const float f = (float)__fma_rn((double)z, 0x1p-32, (double)(int32_t)q); // float32(float64(q) + u), u = z 2^-32 exactly
+#endif
+        o[c] = __fadd_rn(__fmul_rn(d.dx, f), d.low);                             // group.go:308: float32 multiply, then add
+    }
+    // minp.go:188-196, only for blocks in which it can fire (selects, not branches: the conditions differ from lane to lane)
+    if (d.fix_hi) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float y = __fsub_rn(o[c], L); o[c] = o[c] >= L ? y : o[c]; }
+    }
+    if (d.fix_lo) {
+        // (after the upper test: a value that was >= L is now in [0, L) and is not touched again; one below 0 was not touched above)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const float y = __fadd_rn(o[c], L); o[c] = o[c] < 0.0f ? y : o[c]; }
+    }
+    return o;
+}
+
+// Grid stores: a lane's four particles are 48 contiguous bytes, but three 16-byte stores at a 48-byte lane stride make every
+// store instruction touch 24 cache lines a third each.  A wave's 256 particles of one pass -- 3 KB of the grid, contiguous but
+// for the ends of sub-cell rows -- go through a wave-local LDS image (no barrier: a wave's LDS operations complete in order)
+// and leave as three instructions of 64 consecutive 16-byte chunks each; the grid offset of every group of four travels
+// through LDS beside it.
+// vmcnt: a wave's vector-memory operations complete in issue order and the counter counts stores too.  The words of vtile
+// v + 1 are requested BEFORE the grid stores of vtile v are issued, so waiting for them must not wait for those stores
+// (measured, round 3: with `s_waitcnt vmcnt(0)` in front of the staging -- what the compiler emits as soon as a load or a store
+// sits in divergent or conditional control flow, because it can then no longer count -- the launch took 573 us with the stores,
+// 370 us without them, and not a microsecond less when the dither was removed).  Hence every load and store of the loop is an
+// UNCONDITIONAL raw-buffer operation in straight-line code: lanes with nothing to do are given an offset outside the buffer
+// (a load then returns zero and a store is dropped, neither makes a request), and the compiler's own count is exact.
+constexpr int kV3ImgDw = 64 * 12 + 64;          // dwords per wave: the image and the 64 grid offsets
+constexpr uint32_t kV3NoStore = 0xfffff800u;    // a grid offset beyond every buffer's range (they end below 0xfffff001), also with 32 added
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t v3_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)base;
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+// The aligned 64-bit words that hold vtile t of a stream -> registers (lane i of the workgroup takes words i, i + 256, ...);
+// words past the stream's end read as zero (they only feed elements beyond n, which are never stored).
+template <int NW>
+__device__ __forceinline__ void v3_load_words(u32x2 (&w)[NW], const StreamView& sv, uint32_t t, uint32_t b, int tid) {
+    const int64_t w0 = (int64_t)t * (kVTile / 64) * b;
+    int64_t left = sv.last + 1 - w0;                             // words of the stream from w0 on
+    if (left < 0 || b == 0) left = 0;
+    if (left > NW * 256) left = NW * 256;
+    const __amdgpu_buffer_rsrc_t r = v3_rsrc(sv.a + w0, (uint32_t)left * 8u);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b64(r, (k * 256 + tid) * 8, 0, 0);
+}
+
+template <int NW, bool DB>
 __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restrict__ vec_out, const DevJob* __restrict__ jobs,
-                                                     int periodic, float L) {
-    constexpr int kLW = kTileD / 64 * 32 + 2;                     // 64-bit words of one component's vtile
-    constexpr int kNW = (kLW + 255) / 256;
+                                                     int periodic, float L, int tiles_per_wg) {
     static_assert(kTileD == kVTile, "the stream helpers are written for 2,048-element tiles");
-    __shared__ __attribute__((aligned(16))) uint64_t lw[3][kLW];
-    const int tid = threadIdx.x;
-    const int64_t total = (int64_t)a.s3 * a.tiles_per_sc;
-    int64_t v0 = total * blockIdx.x / gridDim.x;
-    const int64_t v1 = total * (blockIdx.x + 1) / gridDim.x;
+    constexpr int kLW = NW * 256;                                       // 64-bit words of one component's buffer
+    extern __shared__ __attribute__((aligned(16))) uint64_t v3_lds[];    // [1 or 2 buffers][3 components][kLW], then the images
+    const SubcellGeom& gm = a.gm;
+    int64_t v0, v1;
+    if (tiles_per_wg > 0) {
+        // Workgroups in dispatch order walk the sub-cells of one x-row together (sx fastest): the five row segments that make up
+        // one row of the grid are then written at about the same time.  A sub-cell at a time leaves 1,200 of every 6,000 bytes
+        // of the grid's rows to each of five sub-cells processed one after the other, and rows written with such gaps move at
+        // 2.9 TB/s where contiguous ones move at 6.9 (tools/microbench/rw_mix.hip).
+        const uint32_t S = gm.sub_cells, tq_n = (a.tiles_per_sc + tiles_per_wg - 1) / tiles_per_wg;
+        const uint32_t w = blockIdx.x, sx = w % S, q = w / S, tq = q % tq_n, syz = q / tq_n;
+        const uint32_t t0 = tq * tiles_per_wg, t1 = min(t0 + (uint32_t)tiles_per_wg, a.tiles_per_sc);
+        v0 = (int64_t)(sx + S * syz) * a.tiles_per_sc + t0;
+        v1 = v0 + (t1 - t0);
+    } else {
+        const int64_t total = (int64_t)a.s3 * a.tiles_per_sc;
+        v0 = total * blockIdx.x / gridDim.x;
+        v1 = total * (blockIdx.x + 1) / gridDim.x;
+    }
+    int buf = 0;
+    uint32_t* const img = reinterpret_cast<uint32_t*>(v3_lds + (size_t)(DB ? 2 : 1) * 3 * kLW) + wave_id() * kV3ImgDw;
     while (v0 < v1) {
         const uint32_t sc = (uint32_t)(v0 / a.tiles_per_sc);
         int64_t vend = (int64_t)(sc + 1) * a.tiles_per_sc;
         if (vend > v1) vend = v1;
-        uint32_t b[3], mask[3], ka[3], kb[3];
-        int32_t mn[3], pix[3];
-        float low[3], dx[3];
+        V3Dec d[3];
         StreamView sv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const DevJob jb = jobs[(int64_t)k * a.s3 + sc];
-            b[k] = (uint32_t)jb.bits;
-            mask[k] = b[k] == 0 ? 0u : (b[k] == 32 ? ~0u : ((1u << b[k]) - 1u));
-            mn[k] = (int32_t)jb.min; pix[k] = (int32_t)jb.pixels;
-            low[k] = jb.low; dx[k] = jb.dxq;
-            sv[k] = stream_view(jb, b[k]);
-            const uint64_t key = dither_key(jb.seed, jb.block, 0);   // element indices stay below 2^32
-            ka[k] = (uint32_t)key; kb[k] = (uint32_t)(key >> 32);
+            const DevJob& jb = jobs[(int64_t)k * a.s3 + sc];
+            d[k] = v3dec_make(jb, periodic, L);
+            sv[k] = stream_view(jb, d[k].b);
         }
+        // the sub-cell's part of the grid behind one buffer descriptor: offsets are relative to its first particle
+        const uint32_t s2 = gm.sub_cells * gm.sub_cells;
+        const uint32_t sz = sc / s2, sq = sc - sz * s2, sy = sq / gm.sub_cells, sx = sq - sy * gm.sub_cells;
+        const uint32_t base0 = gm.n_sub * (sx + sy * gm.n_file + sz * gm.n_file2);
+        const int64_t gleft = (gm.n - (int64_t)base0) * 12;             // bytes of the grid from there on (host: the sub-cell's span < 2^32)
+        const __amdgpu_buffer_rsrc_t grid_r = v3_rsrc(vec_out + 3 * (int64_t)base0, gleft > 0xfffff000ll ? 0xfffff000u : (uint32_t)gleft);
         // the words of the next vtile are loaded into registers while the current one is extracted
-        uint64_t w[3][kNW];
+        u32x2 w[3][NW];
         {
             const uint32_t t = (uint32_t)(v0 - (int64_t)sc * a.tiles_per_sc);
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (b[k] != 0) load_tile_words<kNW>(w[k], sv[k], (int64_t)t * kVTile, b[k]);
+            for (int k = 0; k < 3; ++k) v3_load_words<NW>(w[k], sv[k], t, d[k].b, (int)threadIdx.x);
+            // Six stores that store nothing (out of range: no request), so that the loop is entered with the same sequence of
+            // outstanding operations -- the words' loads, then six stores -- as its back edge carries: the compiler merges the two
+            // states at the loop header, and with different ones it can only wait for everything (vmcnt(0), i.e. for the grid
+            // stores of the vtile before).
+            const u32x4 nothing = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) __builtin_amdgcn_raw_buffer_store_b128(nothing, grid_r, (int)kV3NoStore, 0, 0);
         }
         for (int64_t v = v0; v < vend; ++v) {
             const uint32_t t = (uint32_t)(v - (int64_t)sc * a.tiles_per_sc);
+            uint64_t* lw = v3_lds + (size_t)buf * 3 * kLW;
+            if (!DB && v != v0) lds_barrier();                          // every wave is done with the words of the vtile before
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                if (b[k] != 0) {
-                    stage_tile_words<kNW>(lw[k], w[k], b[k]);
-                    if (v + 1 < vend) load_tile_words<kNW>(w[k], sv[k], (int64_t)(t + 1) * kVTile, b[k]);
-                }
+#pragma unroll
+                for (int i = 0; i < NW; ++i) *reinterpret_cast<u32x2*>(lw + k * kLW + i * 256 + threadIdx.x) = w[k][i];
+                v3_load_words<NW>(w[k], sv[k], t + 1, d[k].b, (int)threadIdx.x);    // (past the sub-cell's end: zeros, no request)
             }
             lds_barrier();
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint32_t e = 4 * (tid + 256 * r);
+                const int lane = opaque_tid() & 63;
+                const uint32_t e0 = 4 * (64 * wave_id() + 256 * r);    // the wave's first element of this pass
+                const uint32_t e = e0 + 4 * lane;
                 const uint32_t j = t * kVTile + e;
-                if (j < a.gm.n_sub3) {
-                    sc_f32x4 o[3];
+                // (lanes past the end of the sub-cell -- its last vtile -- compute on whatever the buffers hold and store nothing)
+                sc_f32x4 o[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < 3; ++k)
+                    o[k] = v3_dequant4(d[k], reinterpret_cast<const uint32_t*>(lw + k * kLW), e * d[k].b + d[k].sh, j, L);
+                const sc_f32x4 q0 = {o[0].x, o[1].x, o[2].x, o[0].y}, q1 = {o[1].y, o[2].y, o[0].z, o[1].z},
+                               q2 = {o[2].z, o[0].w, o[1].w, o[2].w};
+                sc_f32x4* ip = reinterpret_cast<sc_f32x4*>(img + 12 * lane);
+                ip[0] = q0; ip[1] = q1; ip[2] = q2;
+                const uint32_t rel = vec3_particle(a, sc, j) - base0;                   // (garbage, and unused, for j >= n_sub^3)
+                img[64 * 12 + lane] = j < gm.n_sub3 ? rel * 12u : kV3NoStore;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t val = b[k] == 0 ? 0u : extract32(reinterpret_cast<const uint32_t*>(lw[k]), e + c, b[k], mask[k], sv[k].sh);
-                            int32_t q = mn[k] + (int32_t)val;                 // group.go:262
-                            if (q < 0) q += pix[k];                           // bound(buf, 0, pixels): FloatGroups are periodic
-                            else if (q >= pix[k]) q -= pix[k];
-#ifdef MNW_DIAG_NO_DITHER      // diagnostic builds only: price the dither
-                            const double u = 0.0;
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t c = 64 * i + lane;                   // chunk of the wave's image
+                    const uint32_t g = __umulhi(c, 0x55555556u), part = c - 3 * g;      // c / 3 for c < 2^31
+                    const u32x4 ch = *reinterpret_cast<const u32x4*>(img + 4 * c);
+                    const uint32_t off = img[64 * 12 + g];
+#ifdef MNW_DIAG_V3_NOSTORE      // diagnostic builds only: price the grid stores
+                    __builtin_amdgcn_raw_buffer_store_b128(ch, grid_r, (int)(ch.x == 0x7fc00001u ? off + 16 * part : kV3NoStore), 0, 0);
 #else
-                            const uint32_t z = dither_bits(j + c, ka[k], kb[k]);
-                            const double u = (double)z * (1.0 / 4294967296.0);
-#endif
-                            const float x = __fadd_rn(__fmul_rn(dx[k], (float)__dadd_rn((double)q, u)), low[k]);   // group.go:308
-                            o[k][c] = wrap_once(x, L, periodic);
-                        }
-                    }
-                    const uint32_t i = vec3_particle(a, sc, j);
-                    MNW_GLOBAL_SC sc_f32x4* p = (MNW_GLOBAL_SC sc_f32x4*)(vec_out + 3 * (int64_t)i);
-                    const sc_f32x4 q0 = {o[0].x, o[1].x, o[2].x, o[0].y}, q1 = {o[1].y, o[2].y, o[0].z, o[1].z},
-                                   q2 = {o[2].z, o[0].w, o[1].w, o[2].w};
-#ifdef MNW_DIAG_NT_STORES      // diagnostic builds only: streaming stores for the grid
-                    __builtin_nontemporal_store(q0, p); __builtin_nontemporal_store(q1, p + 1); __builtin_nontemporal_store(q2, p + 2);
-#else
-                    p[0] = q0; p[1] = q1; p[2] = q2;
+                    __builtin_amdgcn_raw_buffer_store_b128(ch, grid_r, (int)(off + 16 * part), 0, 0);       // (kV3NoStore + 16 part: out of range)
 #endif
                 }
+                // (the next pass overwrites the image: its writes follow these reads in the wave's LDS queue)
             }
-            lds_barrier();
+            if (DB) buf ^= 1;
         }
         v0 = vend;
     }
@@ -1078,7 +1212,25 @@ int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
     const int64_t n_sub = n_file / sub_cells, n3 = n_sub * n_sub * n_sub;
     return sub_cells * sub_cells * sub_cells * ((n3 + kVTile - 1) / kVTile);
 }
-void launch_unpack_vec3(hipStream_t s, int grid, float* vec_out, int64_t n_file, int64_t sub_cells, const DevJob* jobs, int periodic, float L) {
+// max_bits: the widest block of the call (sizes the LDS word buffers and the prefetch registers); double_buffer: two word
+// buffers and one barrier per vtile instead of one and two
+// tiles_per_wg > 0: x-interleaved order, the grid is sub_cells^3 * ceil(T / tiles_per_wg) workgroups (`grid` is ignored)
+void launch_unpack_vec3(hipStream_t s, int grid, float* vec_out, int64_t n_file, int64_t sub_cells, const DevJob* jobs, int periodic, float L,
+                        int max_bits, bool double_buffer, int tiles_per_wg) {
     const Vec3Args a = make_vec3_args(vec_out, n_file, sub_cells);
-    hipLaunchKernelGGL(k_unpack_vec3, dim3(grid), dim3(256), 0, s, a, vec_out, jobs, periodic, L);
+    if (tiles_per_wg > 0) grid = (int)(a.s3 * ((a.tiles_per_sc + tiles_per_wg - 1) / tiles_per_wg));
+    if (max_bits < 1) max_bits = 1;
+    const int words = kVTile / 64 * max_bits + 2;                 // 64-bit words of one component's vtile
+    const int nw = words <= 2 * 256 ? 2 : words <= 3 * 256 ? 3 : 5;
+    const size_t lds = (size_t)(double_buffer ? 2 : 1) * 3 * nw * 256 * sizeof(uint64_t) + (size_t)4 * kV3ImgDw * sizeof(uint32_t);
+#define MNW_LAUNCH_UV3(NWV) do { if (double_buffer) hipLaunchKernelGGL((k_unpack_vec3<NWV, true>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg); \
+                                 else hipLaunchKernelGGL((k_unpack_vec3<NWV, false>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg); } while (0)
+    if (nw == 2) MNW_LAUNCH_UV3(2);
+    else if (nw == 3) MNW_LAUNCH_UV3(3);
+    else MNW_LAUNCH_UV3(5);
+#undef MNW_LAUNCH_UV3
+}
+// the grid offsets of k_unpack_vec3 are 32-bit and relative to a sub-cell's first particle
+bool vec3_unpack_geometry_ok(int64_t n_file, int64_t sub_cells) {
+    return (n_file / sub_cells) * n_file * n_file * 12 < 0xfff00000ll;
 }
