@@ -428,472 +428,540 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// minp.Writer.Vectors with the grid read ONCE (k_encode_reg_vec3): the resident pipeline and tagged-record exchange of
-// k_encode_reg_f32 (its header has the protocol) over vtiles, one stage deeper.  An item = one vtile = 2,048 particles of
-// one sub-cell, all three components (24 KB of the grid, 24 values per lane).
-// The three blocks of a sub-cell have 489 items each at C4's geometry and every workgroup needs all three descriptors every
-// trip, so the statistics are exchanged in TWO levels:
-//   item records   one per (component, vtile), published in the trip in which the vtile arrives;
-//   group records  the fold of kVGroup = 32 consecutive item records of a block, published by EVERY member of the group
-//                  (no leader: whichever member gets there first makes it available) in R copies -- copy d is read only by
-//                  the workgroups whose vtile is in group d (R = groups per block <= 32);
-// a trip reads 3 x (32 + R) records = 4.6 KB for C4, against 3 x 489 = 47 KB for a flat sweep of the item records.
-// A record that is read must have been published a whole trip before: under this kernel's load a memory round trip takes most
-// of a trip (the queues hold ~32 MB), so a read that has to be repeated costs a trip (measured: the group fold placed in
-// the same trip as the publication of its item records, 886 us for C4 against 497 us for the pipeline without any exchange).
-// Hence THREE items per workgroup: the NEW one (registers; its loads were issued a trip ago), the MIDDLE one (registers,
-// statistics published last trip) and the OLD one (LDS, three planes of pixel indices).  Per trip:
-//   all waves    statistics of NEW -> publish its three item records
-//   waves 0..2   (= components x, y, z; wave 3 has no part in this) one pair of record loads at the start of the trip, both
-//                kinds a trip old by then: lanes 0..31 the R group records of OLD's block, lanes 32..63 the item records of
-//                MIDDLE's group.  Upper half -> fold -> publish MIDDLE's group record (the group duty); lower half ->
-//                descriptor of OLD's block -> re-base, pack the component's plane in place, store
-//   all waves    MIDDLE -> quantize -> LDS; NEW becomes MIDDLE; issue the loads of the next vtile
-// No deadlock (unweighted rounds, blocks of at most G vtiles): the duty needs item records only and waits for nothing else; a
-// workgroup reaches the trip of a vtile once the blocks of its earlier vtiles are complete, which are strictly earlier blocks --
-// induction over the blocks in order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the
-// call through k_reduce_vec3 + k_pack_vec3.
-// HBM traffic = algorithmic: 12 B/particle read + the streams (+ the records, 13 % of that at C4).
+// minp.Writer.Vectors with the grid read ONCE: k_encode_reg_vec3 (round 3 form).
+//
+// An item = one vtile = 2,048 particles of one sub-cell, all three components (24 KB of the grid, 24 values per lane); items
+// are dealt in rounds over the G resident workgroups (item i to workgroup i mod G).  A sub-cell's three blocks have T items
+// each (489 at C4's geometry), and a block's width is known only when all of them have been seen.  Round 2's kernel let every
+// workgroup fold the records of its block's items (in two levels, 3 x (32 + R) records per trip and workgroup): bit-exact and
+// no faster than two passes over the grid, because at ~40 vector instructions per element it was bound by instruction issue.
+// This form is written against the measured instruction costs (tools/microbench/valu_cost.hip) and does per element only
+// what cannot be done per item, per sub-cell or per launch:
+//   * Quantize on arrival, statistics on the pixel indices (integers): min / max of q and of q - pixels/2 (mod 2^32) with
+//     three-input min / max, one subtraction, and one float addition that carries NaN / Inf -- 7 instructions per element
+//     where the float statistics took 12.  The float64-multiply quotient (k_pack_f32's header) needs no per-element guard for
+//     the denormal range: a quotient down there quantizes to 0 or -1, so a wave whose minimum is <= 0 reloads its floats and
+//     redoes that component with the IEEE division (rare: only vtiles that touch the bottom of the range).
+//   * ONE workgroup per sub-cell derives its three descriptors: the one that holds the sub-cell's last vtile sweeps the
+//     sub-cell's 3 T item records a trip after it published its own, and publishes three 16-byte descriptor records; everybody
+//     else reads 16 bytes per component and trip instead of folding records.
+//   * Three items per workgroup as before (a record that is read must be a trip old): F, floats in flight for the next trip;
+//     Q, the pixel indices of the item quantized in this trip (registers; the quantization moves F to Q, so nothing is copied);
+//     and the OLD item, parked in LDS as three planes in the pack core's staging layout.
+// Per trip:   1. waves 0..2 pack OLD's component w from its plane with the descriptor requested a trip ago and store the words
+//                (wave-local); wave 3 does the sweep duty if the item in Q is its sub-cell's last
+//             barrier -- 2. Q -> planes  3. F (arrived) -> quantize -> Q, lane statistics, wave reduction -> LDS
+//                        4. request the descriptor of the sub-cell now in the planes, then the next item's floats -> F
+//             barrier -- 5. wave 3 publishes the item's three records
+// vmcnt (see k_unpack_vec3): every wave issues the SAME vector-memory instructions every trip -- eight 16-byte stores and one
+// byte store of packed words, one descriptor load, six loads of floats, one record store -- as unconditional raw-buffer
+// operations whose idle lanes (or whole idle waves) carry an out-of-range offset, so that the compiler's counted waits let the
+// stores of a trip stay in flight under the loads that were issued before them.
+// No deadlock (blocks of at most G vtiles, all G workgroups resident): a workgroup publishes item i before it needs anything
+// that depends on item i, the descriptor of a sub-cell needs item records only, and the workgroup that derives it reaches
+// that trip once the descriptors of its earlier items are out, which are earlier sub-cells -- induction over the sub-cells in
+// order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the call through
+// k_reduce_vec3 + k_pack_vec3.   HBM traffic = algorithmic: 12 B/particle read + the streams (+ 96 B of records per item).
 // ------------------------------------------------------------------------------------------------
-constexpr int kVGroup = 32;                 // vtiles per record group
-
-// all the records of a launch behind one buffer descriptor: lane-specific indices
-__device__ __forceinline__ void rec_prefetch_any(const ItemRec* base, uint32_t total_recs, int64_t idx, u32x4& a, u32x4& b) {
-    const uint64_t p = (uint64_t)base;
-    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)(total_recs * (uint32_t)sizeof(ItemRec)), 0x00020000);
-    const int off = (int)((uint32_t)idx * (uint32_t)sizeof(ItemRec));
-    a = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
-    b = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 16);
-}
-
+#if defined(MNW_STAMPS)     // diagnostic builds only (tools/microbench/vec3_stamps.hip): how often a descriptor is late, per workgroup (wave 0)
+__device__ unsigned long long* g_v3_diag = nullptr;
+#define MNW_V3_COUNT_DECL unsigned long long v3c_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MNW_V3_COUNT(i) { v3c_[i] += 1; }
+#define MNW_V3_COUNT_FLUSH if (g_v3_diag && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_v3_diag[blockIdx.x * 8 + i_] += v3c_[i_]; }
+#else
+#define MNW_V3_COUNT_DECL
+#define MNW_V3_COUNT(i)
+#define MNW_V3_COUNT_FLUSH
+#endif
 struct Vec3RegArgs {
     Vec3Args a;
-    ItemRec* recs;            // [3 s3][tiles_per_sc]
-    ItemRec* grecs;           // [3 s3][R reader groups][R]
+    ItemRec* recs;            // [3 s3][T] item records, then [3 s3] 16-byte descriptor records
     uint32_t gen;
-    uint32_t R;               // groups per block
     uint32_t* abort_flag;
     uint32_t* abort_host;
     int64_t drop_item;        // test hook: the records of that vtile are never published
-    uint32_t m_row, m_nsub;   // floor(2^32 / d) + 1 for d = n_sub / 4 and d = n_sub: x / d == umulhi(x, m) whenever x d < 2^32
-    uint32_t m_s, m_s2;       // the same for d = sub_cells and sub_cells^2
+    uint32_t n_sweepers;      // workgroups at the end of the grid that derive the sub-cells' descriptors
+    int weighted;             // 0: every round is a whole grid; k > 0: round sizes from kRoundTable[k - 1] (k_encode_reg_f32: the quarters of the grid run at different speeds)
+    uint32_t m_T;             // floor(2^32 / T) + 1: item / T == umulhi(item, m_T) for item T < 2^32
 };
 
-// vec3_load for this kernel: the sub-cell's origin is wave-uniform (scalar arithmetic), the lane's part of the index needs two
-// divisions by launch constants, done as multiply-high (exact here: n_sub <= 128, see the launch wrapper).  j4 = element / 4.
-__device__ __forceinline__ Vec3Group vec3_load_m(const Vec3RegArgs& ra, uint32_t base0, uint32_t j4) {
-    const SubcellGeom& gm = ra.a.gm;
-    Vec3Group g;
-    g.valid = 4 * j4 < gm.n_sub3;
-    if (g.valid) {
-        const uint32_t rowlen = gm.n_sub >> 2;
-        const uint32_t row = __umulhi(j4, ra.m_row), jx4 = j4 - row * rowlen;          // row = jy + n_sub jz
-        const uint32_t jz = __umulhi(row, ra.m_nsub), jy = row - jz * gm.n_sub;
-        const uint32_t i = base0 + 4 * jx4 + jy * gm.n_file + jz * gm.n_file2;
-        const MNW_GLOBAL_SC sc_f32x4* p = (const MNW_GLOBAL_SC sc_f32x4*)(ra.a.vec + 3 * (int64_t)i);
-        g.u = p[0]; g.v = p[1]; g.w = p[2];
-    }
-    return g;
-}
+constexpr uint32_t kV3Oob = 0xfffff800u;        // an offset beyond every buffer of this kernel, also with a few hundred bytes added
 
-// Twelve per-lane values -> their twelve wave-wide maxima, in lanes 0..3 (three each: lane q holds the values 6 (q & 1) + 3 (q >> 1) + {0, 1, 2}).
-// Two halving steps inside each quad (a lane keeps half of its values and takes the partner's half of those), then the three
-// survivors are folded over the quads of a row (row rotations keep the lane's position in its quad), then over the rows:
-// 42 vector instructions against 12 x 16 for one full-wave reduction per value.
-__device__ __forceinline__ void wave_max12(const float (&m)[12], float (&out)[3]) {
-    auto dpp = [](float x, auto ctrl) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+// Twelve per-lane values -> their twelve wave-wide unsigned maxima, in lanes 0..3 (three each: lane q holds the values
+// 6 (q & 1) + 3 (q >> 1) + {0, 1, 2}).  Two halving steps inside each quad (a lane keeps half of its values and takes the
+// partner's half of those), then the three survivors are folded over the quads of a row and over the rows.
+__device__ __forceinline__ void wave_max12_u32(const uint32_t (&m)[12], uint32_t (&out)[3]) {
+    auto dpp = [](uint32_t x, auto ctrl) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, decltype(ctrl)::value, 0xf, 0xf, true); };
     const int l = lane_id();
     const bool b0 = l & 1, b1 = l & 2;
-    float r6[6];
+    uint32_t r6[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const float keep = b0 ? m[i + 6] : m[i], send = b0 ? m[i] : m[i + 6];
-        r6[i] = fmaxf(keep, dpp(send, std::integral_constant<int, 0xB1>{}));          // quad_perm [1,0,3,2]
+        const uint32_t keep = b0 ? m[i + 6] : m[i], send = b0 ? m[i] : m[i + 6];
+        r6[i] = max(keep, dpp(send, std::integral_constant<int, 0xB1>{}));            // quad_perm [1,0,3,2]
     }
-    float r3[3];
+    uint32_t r3[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float keep = b1 ? r6[i + 3] : r6[i], send = b1 ? r6[i] : r6[i + 3];
-        r3[i] = fmaxf(keep, dpp(send, std::integral_constant<int, 0x4E>{}));          // quad_perm [2,3,0,1]
+        const uint32_t keep = b1 ? r6[i + 3] : r6[i], send = b1 ? r6[i] : r6[i + 3];
+        r3[i] = max(keep, dpp(send, std::integral_constant<int, 0x4E>{}));            // quad_perm [2,3,0,1]
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float v = r3[i];
-        v = fmaxf(v, dpp(v, std::integral_constant<int, 0x124>{}));                   // row_ror:4
-        v = fmaxf(v, dpp(v, std::integral_constant<int, 0x128>{}));                   // row_ror:8
-        v = fmaxf(v, __shfl_xor(v, 16));
-        v = fmaxf(v, __shfl_xor(v, 32));
+        uint32_t v = r3[i];
+        v = max(v, dpp(v, std::integral_constant<int, 0x124>{}));                     // row_ror:4
+        v = max(v, dpp(v, std::integral_constant<int, 0x128>{}));                     // row_ror:8
+        v = max(v, (uint32_t)__shfl_xor((int)v, 16));
+        v = max(v, (uint32_t)__shfl_xor((int)v, 32));
         out[i] = v;
     }
 }
 
+// The statistics of a set of pixel indices, all four as unsigned maxima ("max form": what the item records hold and what
+// every fold is): 0: max q, 1: min q, 2: max of u = q - h mod 2^32, 3: min of u (h = pixels / 2: for q in [0, pixels) the
+// indices below h are exactly the u >= 2^32 - h, so max u belongs to the largest q below h and min u to the least q at or
+// above it -- the two extra statistics of periodicMin's second arc, make_desc_f32).
+__device__ __forceinline__ uint32_t v3_enc_max(int32_t mx) { return (uint32_t)mx ^ 0x80000000u; }
+__device__ __forceinline__ uint32_t v3_enc_min(int32_t mn) { return ~((uint32_t)mn ^ 0x80000000u); }
+__device__ __forceinline__ int32_t v3_dec_max(uint32_t w) { return (int32_t)(w ^ 0x80000000u); }
+__device__ __forceinline__ int32_t v3_dec_min(uint32_t w) { return (int32_t)(~w ^ 0x80000000u); }
+
 // what a block's descriptor needs of its job, the same for every sub-cell of a component (LDS copy, made once)
 struct Vec3JobPar {
     float low, dxq;
-    int periodic, pad;
     int64_t pixels, n, cap;
 };
 
-// Lanes 0..11 of one wave: the three descriptors of a sub-cell at once (lane = 4 component + word; desc_from_sweep_f32 across
-// three quads).  v = the lane's swept statistic, bad = a member of the lane's block was not finite.  The granule of component c
-// comes back in lanes 4c..4c+3; lane 4c writes the block's metadata if asked to.
-__device__ __forceinline__ uint64_t desc3_from_sweep_f32(const Vec3JobPar& jp, int64_t j, uint32_t v, bool bad, Meta* __restrict__ meta, bool write_meta) {
+// a block's descriptor from its swept statistics (max form) -- the decisions of make_desc_f32 on integers
+__device__ __forceinline__ Desc v3_desc(const Vec3JobPar& jp, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, bool bad) {
     Desc d = {0, 0, 0, 0, 0};
-    const int l = lane_id(), r = l & 3, q0 = l & ~3;
-    const uint32_t key = (r & 1) ? ~v : v;
-    int64_t ql = 0;
-    const bool okl = quant_i64(funkey(key), jp.low, jp.dxq, &ql);
-    const bool has_lo = __shfl(v, q0 + 2) != 0, has_hi = __shfl(v, q0 + 3) != 0;
-    const uint32_t okmask = (uint32_t)(__ballot(okl) >> q0) & 15u;
-    const bool ok = (okmask & 3) == 3 && (!has_lo || (okmask & 4)) && (!has_hi || (okmask & 8));
-    const int64_t mx0 = __shfl(ql, q0), mn0 = __shfl(ql, q0 + 1), mxlo = __shfl(ql, q0 + 2), mnhi = __shfl(ql, q0 + 3);
-    uint64_t maxdelta = 0;
-    if (bad || !ok) {
-        d.status = (int)kNeedsExact;
-    } else if (jp.periodic == 1) {
-        if (mn0 < 0 || mx0 >= jp.pixels || jp.pixels > 0x7fffffffll) d.status = (int)kNeedsExact;
-        else {
-            const int64_t h = jp.pixels / 2;
-            if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-            else if (has_lo && has_hi && (mxlo + jp.pixels) - mnhi + 1 <= h) {
-                d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jp.pixels - mnhi);
-            } else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-        }
-    } else {
-        if (mn0 < -0x80000000ll || mx0 > 0x7fffffffll) d.status = (int)kNeedsExact;
-        else { d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-    }
-    if (d.status == 0) {
-        d.bits = precision_needed(maxdelta);
-        d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jp.n);
-        if (d.nbytes > jp.cap) d.status = -5;
-    }
-    if (write_meta && r == 0) {
-        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
-        meta[j] = m;
-    }
-    return gran_encode(d);
+    const int64_t mx0 = v3_dec_max(w0), mn0 = v3_dec_min(w1);
+    const uint32_t umx = w2, umn = ~w3;
+    // (a quotient beyond int32 saturates the conversion: INT32_MAX >= pixels and INT32_MIN < 0 send the block to the exact path too)
+    if (bad || mn0 < 0 || mx0 >= jp.pixels || jp.pixels > 0x7fffffffll) { d.status = (int)kNeedsExact; return d; }
+    const int64_t h = jp.pixels / 2;
+    uint64_t maxdelta;
+    const bool has_lo = (int32_t)umx < 0, has_hi = (int32_t)umn >= 0;
+    const int64_t mxlo = (int64_t)(uint32_t)(umx + (uint32_t)h), mnhi = (int64_t)(uint32_t)(umn + (uint32_t)h);
+    if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+    else if (has_lo && has_hi && (mxlo + jp.pixels) - mnhi + 1 <= h) { d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jp.pixels - mnhi); }
+    else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
+    d.bits = precision_needed(maxdelta);
+    d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jp.n);
+    if (d.nbytes > jp.cap) d.status = -5;
+    return d;
 }
 
-#ifndef MNW_V3_DIAG
-#define MNW_V3_DIAG 0          // diagnostic builds only (wrong output): 1 = never wait for a group record, 2 = no group duty, 4 = duty without waiting
-#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t v3_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t p = (uint64_t)base;
+    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
 
-__global__ __launch_bounds__(256, 3) void k_encode_reg_vec3(Vec3RegArgs ra, const DevJob* __restrict__ jobs, Meta* __restrict__ meta) {
+// DEEP: one more item in registers (P, quantized two trips ago) between Q and the planes: a descriptor is then asked for two whole
+// trips after its sub-cell's last record instead of one, at 168 registers and three workgroups per CU instead of 128 and four
+template <bool DEEP>
+__global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegArgs ra, const DevJob* __restrict__ jobs, Meta* __restrict__ meta) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * kVPlane];
-    __shared__ float red[12][4];                         // NEW's statistics per wave, all as maxima (minima negated)
+    __shared__ uint32_t red[12][4];                      // the item's statistics per wave, max form
     __shared__ int redbad[4];
-    __shared__ uint32_t swp[3][5];                       // OLD's block per component: the four swept statistics, flags
-    __shared__ uint64_t gran_s[3];
     __shared__ Vec3JobPar jpar[3];
     __shared__ int abort_s;
     const Vec3Args& a = ra.a;
+    const SubcellGeom& gm = a.gm;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(wave_id()), l = lane_id();    // (uniform: the roles below are scalar branches)
-    const uint32_t T = a.tiles_per_sc, R = ra.R, s3 = a.s3, gen = ra.gen;
+    const uint32_t T = a.tiles_per_sc, s3 = a.s3, gen = ra.gen;
     const uint32_t total = s3 * T;                       // (below 2^26: the host's record budget)
-    const uint32_t n_item_recs = 3u * s3 * T, n_group_recs = 3u * s3 * R * R;
+    const uint32_t n_item_recs = 3u * s3 * T;
     // a round moves every workgroup on by G items = dsc sub-cells and dt vtiles
-    const uint32_t G = gridDim.x, dsc = G / T, dt = G - dsc * T;
+    const uint32_t G = gridDim.x - ra.n_sweepers;          // (the last n_sweepers workgroups hold no items)
     if (tid < 3) {
         const DevJob& jb = jobs[tid * s3];
-        Vec3JobPar p = {jb.low, jb.dxq, jb.periodic, 0, jb.pixels, jb.n, jb.cap};
+        Vec3JobPar p = {jb.low, jb.dxq, jb.pixels, jb.n, jb.cap};
         jpar[tid] = p;
     }
     if (tid == 0) abort_s = 0;
     // the quantization constants of the three components (the same for every sub-cell: mnw_vectors_encode fills them so)
-    float qlow[3], qdx[3], qxh[3];
+    float qlow[3], qdx[3];
     double qrdx[3];
+    uint32_t qh[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * s3]; qlow[k] = jb.low; qdx[k] = jb.dxq; qrdx[k] = jb.rdx; qxh[k] = jb.xh; }
+    for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * s3]; qlow[k] = jb.low; qdx[k] = jb.dxq; qrdx[k] = jb.rdx; qh[k] = (uint32_t)(jb.pixels / 2); }
+    // everything the launch exchanges behind one buffer descriptor: item records, then the descriptor records
+    const __amdgpu_buffer_rsrc_t rec_r = v3_rsrc(ra.recs, (n_item_recs * 2u + 3u * s3) * 16u);
+    const uint32_t desc_off0 = n_item_recs * 32u;
 
-    Vec3Group gn[2], gm[2];                             // the NEW item (in flight / just arrived) and the MIDDLE one
-    auto issue = [&](uint32_t sc, uint32_t t) {
-        // (scalar: the item is wave-uniform; sc < 2^15, so the divisions by sub_cells are multiply-highs as well)
-        const uint32_t S = a.gm.sub_cells;
-        const uint32_t sz = __umulhi(sc, ra.m_s2), q = sc - sz * S * S, sy = __umulhi(q, ra.m_s), sx = q - sy * S;
-        const uint32_t base0 = a.gm.n_sub * (sx + sy * a.gm.n_file + sz * a.gm.n_file2);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) gn[r] = vec3_load_m(ra, base0, t * (kVTile / 4) + tid + 256 * r);
-    };
-    // MIDDLE -> pixel indices, in place (its floats are not needed once its statistics are out): arithmetic only
-    auto quantize_mid = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            Vec3Group& g = gm[r];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float xv[3] = {g.get(0, c), g.get(1, c), g.get(2, c)};
-                uint32_t qv[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float rq = quant_mul(xv[k], qlow[k], qrdx[k]);
-                    if (__builtin_expect(__builtin_amdgcn_classf(rq, 0x90), 0)) rq = __fdiv_rn(__fsub_rn(xv[k], qlow[k]), qdx[k]);
-                    qv[k] = g.valid ? (uint32_t)cvt_floor_i32(rq) : 0u;
-                }
-                g.set(0, c, __uint_as_float(qv[0])); g.set(1, c, __uint_as_float(qv[1])); g.set(2, c, __uint_as_float(qv[2]));
+    // ---- sweepers: the last ra.n_sweepers workgroups of the grid hold no items.  Sweeper j derives the descriptors of the sub-cells
+    // j, j + n_sweepers, ...: it waits for the sub-cell's last record, folds the 3 T item records (all four waves; again until none
+    // is missing), and lanes 0..2 of wave 3 decide and publish the three descriptor records and the blocks' metadata.  Nobody's
+    // pipeline stands still for this: when the workgroup that holds a sub-cell's last vtile did it, its sweep -- two dependent
+    // round trips and a wait for the slowest of 489 workgroups -- made it the straggler of the next rounds, whose own records
+    // the next sub-cells' owners then waited for: every round paid for a sweep (measured: 80 % of the descriptor requests came
+    // back empty, 4.7 us of every 11 us trip were spent polling).
+    if (blockIdx.x >= G) {
+        // (the sweepers are the youngest waves of their CUs, and the hardware favours a CU's oldest: without a raised priority a
+        // sweep waits behind the item workgroups' instructions)
+        __builtin_amdgcn_s_setprio(3);
+        for (uint32_t sc_ = blockIdx.x - G; sc_ < s3; sc_ += ra.n_sweepers) {
+            uint32_t spins = 0;
+            const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+            // a hint that the sub-cell is (nearly) complete: the last word of its last vtile's records
+            for (;;) {
+                const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rec_r, (int)(((2u * s3 + sc_) * T + (T - 1)) * 32u + 24u), 0, 16);
+                if (((w.y | kRecBad) ^ (gen | kRecBad)) == 0) break;
+                if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; break; }
             }
-        }
-    };
-    // The record loads of a trip (waves 0..2, component wv), issued at the end of the trip before, ahead of the loads of the next
-    // item, so that they are back when those are.  Lanes 0..31: the group records of (osc_, ot_)'s block, the copy row of that vtile's
-    // own group -- published during the trip that is ending; lanes 32..63: the item records of (msc_, mt_)'s group -- published at
-    // its start.  Both arrays sit behind one buffer descriptor (the group records follow the item records).
-    u32x4 ga, gb;
-    bool mine = false;
-    auto issue_records = [&](bool old_, uint32_t osc_, uint32_t ot_, bool mid_, uint32_t msc_, uint32_t mt_) {
-        mine = false;
-        if (wv < 3) {
-            // (32-bit, scalar but for the lane number, which is taken through opaque_tid: nothing lane-specific is kept across the trip)
-            const int lo = opaque_tid() & 63;
-            const uint32_t mfirst_ = mt_ / kVGroup * kVGroup;
-            const int mcnt_ = (int)(T - mfirst_ < (uint32_t)kVGroup ? T - mfirst_ : (uint32_t)kVGroup);
-            const uint32_t gbase = n_item_recs + ((uint32_t)(wv * s3 + osc_) * R + ot_ / kVGroup) * R;
-            const uint32_t ibase = (uint32_t)(wv * s3 + msc_) * T + mfirst_ - 32u;
-            const bool lower = lo < 32;
-            mine = lower ? (old_ && lo < (int)R) : (mid_ && lo - 32 < mcnt_ && !(MNW_V3_DIAG & 2));
-            if (mine) rec_prefetch_any(ra.recs, n_item_recs + n_group_recs, (int64_t)((lower ? gbase : ibase) + (uint32_t)lo), ga, gb);
-        }
-    };
-    // NEW, MIDDLE, OLD as (sub-cell, vtile)
-    uint32_t sc = blockIdx.x / T, t = blockIdx.x - sc * T, msc = 0, mt = 0, osc = 0, ot = 0;
-    bool have_new = blockIdx.x < total, have_mid = false, have_old = false;
-    if (have_new) issue(sc, t);
-    MNW_STAMP_DECL
-    MNW_STAMP_START
-    lds_barrier();
-
-    while (have_new || have_mid || have_old) {
-        uint32_t nsc = sc + dsc, nt = t + dt;
-        if (nt >= T) { nt -= T; ++nsc; }
-        const bool have_next = have_new && nsc < s3;
-
-        // ---- 1. (the record loads of this trip were issued at the end of the previous one, ahead of NEW's loads: see 5)
-        // NEW is complete from here on, on every path: the compiler waits once, here, not wherever NEW is touched next
+            lds_barrier();
+            if (abort_s) return;
+            for (;;) {
+                uint32_t acc[12];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) asm volatile("" :: "v"(gn[r].u), "v"(gn[r].v), "v"(gn[r].w));
-        const uint32_t mgrp = mt / kVGroup, mfirst = mgrp * kVGroup;
-        const int mcnt = (int)(T - mfirst < (uint32_t)kVGroup ? T - mfirst : (uint32_t)kVGroup);
-
-        // ---- 2. statistics of NEW, per component (as k_reduce_vec3), all twelve as maxima
-        if (have_new) {
-            float m12[12];
-            bool nonfinite = false;
+                for (int i = 0; i < 12; ++i) acc[i] = 0;
+                uint32_t missing = 0, anybad = 0;
+                for (uint32_t t0 = 0; t0 < T; t0 += 512) {
+                    u32x4 ra_[2][3], rb_[2][3];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) m12[k] = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const Vec3Group& g = gn[r];
-                if (g.valid) {
-#pragma unroll
-                    for (int c = 0; c < 4; c += 2) {
-                        const float v0[3] = {g.get(0, c), g.get(1, c), g.get(2, c)}, v1[3] = {g.get(0, c + 1), g.get(1, c + 1), g.get(2, c + 1)};
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t tt = t0 + 256u * h + (uint32_t)opaque_tid();
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
-                            nonfinite |= __builtin_amdgcn_classf(v0[k], 0x207) | __builtin_amdgcn_classf(v1[k], 0x207);
-                            m12[4 * k] = max3_raw(m12[4 * k], -v0[k], -v1[k]);                      // -min
-                            m12[4 * k + 1] = max3_raw(m12[4 * k + 1], v0[k], v1[k]);                 // max
-                            const bool l0 = v0[k] < qxh[k], l1 = v1[k] < qxh[k];
-                            m12[4 * k + 2] = max3_raw(m12[4 * k + 2], l0 ? v0[k] : -INFINITY, l1 ? v1[k] : -INFINITY);     // max below the split
-                            m12[4 * k + 3] = max3_raw(m12[4 * k + 3], l0 ? -INFINITY : -v0[k], l1 ? -INFINITY : -v1[k]);   // -min at / above it
+                            const int off = (int)(tt < T ? (((uint32_t)k * s3 + sc_) * T + tt) * 32u : kV3Oob);
+                            ra_[h][k] = __builtin_amdgcn_raw_buffer_load_b128(rec_r, off, 0, 16);
+                            rb_[h][k] = __builtin_amdgcn_raw_buffer_load_b128(rec_r, off + 16, 0, 16);
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t tt = t0 + 256u * h + (uint32_t)opaque_tid();
+                        if (tt < T) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const uint32_t tg = ra_[h][k].y | ra_[h][k].w | rb_[h][k].y | rb_[h][k].w, ta = ra_[h][k].y & ra_[h][k].w & rb_[h][k].y & rb_[h][k].w;
+                                missing |= ((tg | kRecBad) ^ (gen | kRecBad)) | ((ta | kRecBad) ^ (gen | kRecBad));
+                                anybad |= (tg >> 31) << k;
+                                acc[4 * k] = max(acc[4 * k], ra_[h][k].x); acc[4 * k + 1] = max(acc[4 * k + 1], ra_[h][k].z);
+                                acc[4 * k + 2] = max(acc[4 * k + 2], rb_[h][k].x); acc[4 * k + 3] = max(acc[4 * k + 3], rb_[h][k].z);
+                            }
                         }
                     }
                 }
+                uint32_t o3[3];
+                wave_max12_u32(acc, o3);
+                const uint32_t wbad = (__any(anybad & 1u) ? 1u : 0u) | (__any(anybad & 2u) ? 2u : 0u) | (__any(anybad & 4u) ? 4u : 0u) | (__any(missing != 0) ? 8u : 0u);
+                if (l < 4) {
+                    const int base = 6 * (l & 1) + 3 * (l >> 1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) red[base + i][wv] = o3[i];
+                }
+                if (l == 0) redbad[wv] = (int)wbad;
+                lds_barrier();
+                const uint32_t flags = (uint32_t)(redbad[0] | redbad[1] | redbad[2] | redbad[3]);
+                if ((flags & 8u) == 0) {
+                    if (tid >= 192 && tid < 195) {                 // lanes 0..2 of wave 3: component tid - 192
+                        const int k = tid - 192;
+                        uint32_t w4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = max(max(red[4 * k + j][0], red[4 * k + j][1]), max(red[4 * k + j][2], red[4 * k + j][3]));
+                        const Desc d = v3_desc(jpar[k], w4[0], w4[1], w4[2], w4[3], ((flags >> k) & 1u) != 0);
+                        const int64_t j = (int64_t)k * s3 + sc_;
+                        Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
+                        meta[j] = m;
+                        const uint32_t code = d.status == 0 ? 0u : d.status == (int)kNeedsExact ? 1u : d.status == -5 ? 2u : 3u;
+                        const uint32_t info = (uint32_t)d.bits | ((d.pmin == d.imin) ? 0x80u : 0u) | (code << 8);
+                        const u32x4 rec = {(uint32_t)(int32_t)d.imin, gen, info, gen};
+                        __builtin_amdgcn_raw_buffer_store_b128(rec, rec_r, (int)(desc_off0 + (uint32_t)j * 16u), 0, 16);
+                    }
+                    lds_barrier();                               // (red / redbad are free again)
+                    break;
+                }
+                if (wv == 0 && poll_abort(spins, t_start, ra.abort_flag, ra.abort_host) && l == 0) abort_s = 1;
+                lds_barrier();
+                if (abort_s) return;
             }
-            float o3[3];
-            wave_max12(m12, o3);
+        }
+        return;
+    }
+
+    // origin (particle index) of a sub-cell: scalar
+    auto origin = [&](uint32_t sc_) {
+        const uint32_t S = gm.sub_cells, s2 = S * S;
+        const uint32_t sz = sc_ / s2, q_ = sc_ - sz * s2, sy = q_ / S, sx = q_ - sy * S;
+        return gm.n_sub * (sx + sy * gm.n_file + sz * gm.n_file2);
+    };
+    // grid offset (bytes, relative to the sub-cell's origin) of the group of four particles that starts at element j; out of range
+    // past the end of the sub-cell
+    auto group_off = [&](uint32_t j) -> uint32_t {
+        const uint32_t j4 = j >> 2, rowlen = gm.n_sub >> 2;
+        const uint32_t row = __umulhi(j4, a.m_row), jx4 = j4 - row * rowlen;              // row = jy + n_sub jz
+        const uint32_t jz = __umulhi(row, a.m_nsub), jy = row - jz * gm.n_sub;
+        const uint32_t rel = 4 * jx4 + jy * gm.n_file + jz * gm.n_file2;
+        return j < gm.n_sub3 ? rel * 12u : kV3Oob;
+    };
+    // the floats of vtile (sc_, t_): lane = two groups of four particles, three 16-byte loads each (zeros, and no request, past the end)
+    sc_f32x4 F[6];
+    auto issue_floats = [&](bool have, uint32_t sc_, uint32_t t_) {
+        const uint32_t b0 = origin(sc_);
+        const int64_t left = (gm.n - (int64_t)b0) * 12;
+        const __amdgpu_buffer_rsrc_t r = v3_rsrc(a.vec + 3 * (int64_t)b0, !have ? 0u : left > 0xfffff000ll ? 0xfffff000u : (uint32_t)left);
+        const int ot = opaque_tid();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint32_t off = group_off(t_ * kVTile + 4 * (uint32_t)(ot + 256 * g));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                F[3 * g + i] = __builtin_bit_cast(sc_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16 * i), 0, 0));
+        }
+    };
+    // the descriptor record of component wv (waves 0..2) of sub-cell sc_: {imin, tag, info, tag}
+    u32x4 dsc_rec;
+    auto issue_desc = [&](bool have, uint32_t sc_) {
+        const uint32_t k = wv < 3 ? wv : 0;
+        dsc_rec = __builtin_amdgcn_raw_buffer_load_b128(rec_r, (int)(have ? desc_off0 + (k * s3 + sc_) * 16u : kV3Oob), 0, 16);     // sc1
+    };
+
+    // items as (sub-cell, vtile): N = the one whose floats are in flight, Q = quantized in the last trip, O = parked in LDS
+    // Item hand-out as in k_encode_reg_f32: in round k the workgroups [0, size_k) take the items base_k + w; with `weighted` the
+    // round sizes cycle through a table in quarters of the grid (no two partial rounds adjacent: two consecutive items of a
+    // workgroup stay at least a whole grid, hence at least T items, apart)
+    const int weighted = ra.weighted;
+    const uint32_t unit = weighted ? G / 4 : G;
+    int round = 0;
+    uint32_t round_base = 0;
+    auto next_item = [&]() -> uint32_t {
+        for (;;) {
+            round_base += (uint32_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit;
+            round = round + 1 == (weighted ? kRoundCount[weighted - 1] : 1) ? 0 : round + 1;
+            if (round_base >= total) return total;
+            if (blockIdx.x < (uint32_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit) return round_base + blockIdx.x;
+        }
+    };
+    uint32_t nit = blockIdx.x;                          // round 0 is a full one
+    uint32_t nsc = T == 1 ? nit : __umulhi(nit, ra.m_T), nt = nit - nsc * T, qsc = 0, qt = 0, psc = 0, pt = 0, osc = 0, ot = 0;
+    bool have_n = nit < total, have_q = false, have_p = false, have_o = false;
+    uint32_t P[3][8];                                    // DEEP: the item quantized two trips ago
+    uint32_t Q[3][8];                                    // pixel indices of the Q item: component k, the lane's 8 particles
+    issue_desc(false, 0);
+    issue_floats(have_n, nsc, nt);
+    MNW_STAMP_DECL
+    MNW_V3_COUNT_DECL
+    MNW_STAMP_START
+    lds_barrier();
+
+    while (have_n || have_q || have_p || have_o) {
+        // ---- 1. pack the parked item (waves 0..2) | sweep duty (wave 3) ---------------------------------------------------------
+        {
+            // (all waves run the same vector-memory instructions: eight chunk stores and one tail store; wave 3's are out of range)
+            // (lane-specific addresses are built from an opaque lane number inside the trip: hoisted out of the loop they are kept,
+            // and spilled, across everything else)
+            const int lq = opaque_tid() & 63;
+            uint32_t bw = 0, full = 0, rem = 0;
+            int64_t byte0 = 0;
+            uint32_t* plane = lds + (wv < 3 ? wv : 0) * kVPlane;
+            __amdgpu_buffer_rsrc_t dst_r = v3_rsrc(nullptr, 0);
+            if (wv < 3 && have_o) {
+                // the descriptor, requested a trip ago; poll if the sub-cell's owner has not got there yet
+                const Vec3JobPar& jp = jpar[wv];
+                uint32_t imin = dsc_rec.x, info = dsc_rec.z;
+                MNW_V3_COUNT(0);
+                if (__builtin_expect(((dsc_rec.y ^ gen) | (dsc_rec.w ^ gen)) != 0, 0)) {
+                    uint32_t spins = 0;
+                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                    MNW_V3_COUNT(1);
+                    for (;;) {
+                        MNW_V3_COUNT(2);
+                        const u32x4 d2 = __builtin_amdgcn_raw_buffer_load_b128(rec_r, (int)(desc_off0 + ((uint32_t)wv * s3 + osc) * 16u), 0, 16);
+                        if (((d2.y ^ gen) | (d2.w ^ gen)) == 0) { imin = d2.x; info = d2.z; break; }
+                        if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; info = 0x100u; break; }
+                    }
+                }
+                // info: bits 0..6 width, bit 7 pmin == imin, bits 8.. status code (0 ok)
+                imin = (uint32_t)__builtin_amdgcn_readfirstlane((int)imin); info = (uint32_t)__builtin_amdgcn_readfirstlane((int)info);
+                MNW_STAMP(0)      // the descriptor is there (wait for its load, or poll)
+                bw = (info >> 8) == 0 ? (info & 0x7fu) : 0u;
+                if (bw != 0) {
+                    const uint32_t wrapw = (info & 0x80u) ? (uint32_t)jp.pixels : 0u;
+                    uint32_t qq[kGroup];
+#pragma unroll
+                    for (int k8 = 0; k8 < kGroup / 4; ++k8) {
+                        const u32x4 rr = *reinterpret_cast<const u32x4*>(plane + lq * kStride32 + 4 * k8);
+                        qq[4 * k8] = rr.x; qq[4 * k8 + 1] = rr.y; qq[4 * k8 + 2] = rr.z; qq[4 * k8 + 3] = rr.w;
+                    }
+                    const int64_t e0 = (int64_t)ot * kVTile + kGroup * lq;
+                    if (wrapw == 0) {
+#pragma unroll
+                        for (int i = 0; i < kGroup; ++i) qq[i] -= imin;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kGroup; ++i) { const uint32_t r2 = qq[i] - imin; qq[i] = min(r2, r2 + wrapw); }
+                    }
+                    if (e0 + kGroup > jp.n) {
+#pragma unroll
+                        for (int i = 0; i < kGroup; ++i) if (e0 + i >= jp.n) qq[i] = 0;
+                    }
+                    pack_group32_switch(qq, bw, plane + lq * bw);          // (every lane holds its group: the plane can be overwritten)
+                    byte0 = (int64_t)ot * (kVTile / 8) * bw;
+                    const int64_t nbytes = array_bytes(bw, jp.n);
+                    int64_t nbytes_t = (int64_t)(kVTile / 8) * bw;
+                    if (byte0 + nbytes_t > nbytes) nbytes_t = nbytes - byte0;
+                    full = (uint32_t)(nbytes_t >> 4); rem = (uint32_t)(nbytes_t & 15);
+                    const DevJob& jb = jobs[(int64_t)wv * s3 + osc];
+                    dst_r = v3_rsrc((const uint8_t*)jb.dst + byte0, (uint32_t)nbytes_t);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t c = (uint32_t)lq + 64u * i;
+                const u32x4 ch = *reinterpret_cast<const u32x4*>(plane + 4 * c);
+                __builtin_amdgcn_raw_buffer_store_b128(ch, dst_r, (int)(c < full ? 16u * c : kV3Oob), 0, 0);
+            }
+            {
+                const uint32_t wd = plane[4 * full + ((uint32_t)lq >> 2)];
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(wd >> (8 * (lq & 3))), dst_r, (int)((uint32_t)lq < rem ? 16u * full + (uint32_t)lq : kV3Oob), 0, 0);
+            }
+        }
+        MNW_STAMP(1)          // plane read, re-base, pack, stores issued
+        lds_barrier();                                   // every lane holds what it needed of the planes
+        MNW_STAMP(2)          // barrier
+        if (abort_s) break;
+        // ---- 2. Q (DEEP: P, then Q becomes P) -> the planes ----------------------------------------------------------------------------
+        if (DEEP ? have_p : have_q) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint32_t e = 4 * (uint32_t)(opaque_tid() + 256 * g);                // element of the vtile
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const u32x4 v = DEEP ? u32x4{P[k][4 * g], P[k][4 * g + 1], P[k][4 * g + 2], P[k][4 * g + 3]}
+                                         : u32x4{Q[k][4 * g], Q[k][4 * g + 1], Q[k][4 * g + 2], Q[k][4 * g + 3]};
+                    *reinterpret_cast<u32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = v;
+                }
+            }
+        }
+        if (DEEP) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) P[k][i] = Q[k][i];
+        }
+        MNW_STAMP(3)          // park
+        // ---- 3. F -> Q: quantize, statistics ---------------------------------------------------------------------------------------
+        const uint32_t nit2 = have_n ? next_item() : total;
+        const uint32_t nsc2 = T == 1 ? nit2 : __umulhi(nit2, ra.m_T), nt2 = nit2 - nsc2 * T;
+        const bool have_next = nit2 < total;
+        if (have_n) {
+            // component k of particle c of group g is word 3 c + k of the group's three vectors
+            auto fget = [&](int g, int k, int c) -> float { const int i = 3 * c + k; return F[3 * g + (i >> 2)][i & 3]; };
+            const bool partial = (nt + 1) * (uint32_t)kVTile > gm.n_sub3;                 // the sub-cell's last, short vtile (uniform)
+            uint32_t m12[12];
+            float nansum = 0.0f;
+            bool redo[3] = {false, false, false};
+            // (two instantiations: the whole-vtile one has no per-lane validity in it -- a select per element costs as much as the
+            // statistics -- the other is the sub-cell's last vtile)
+            auto quantize = [&](auto whole) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+                    uint32_t umn = 0xffffffffu, umx = 0u;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const bool valid = decltype(whole)::value || nt * (uint32_t)kVTile + 4 * (uint32_t)(opaque_tid() + 256 * g) < gm.n_sub3;
+                        int32_t q4[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float rq = quant_mul(fget(g, k, c), qlow[k], qrdx[k]);
+                            nansum = __fadd_rn(nansum, valid ? rq : 0.0f);
+                            q4[c] = cvt_floor_i32(rq);
+                            Q[k][4 * g + c] = valid ? (uint32_t)q4[c] : 0u;
+                        }
+                        if (valid) {
+                            const uint32_t u0 = (uint32_t)q4[0] - qh[k], u1 = (uint32_t)q4[1] - qh[k], u2 = (uint32_t)q4[2] - qh[k], u3 = (uint32_t)q4[3] - qh[k];
+                            mn = min(min(mn, min(q4[0], q4[1])), min(q4[2], q4[3]));
+                            mx = max(max(mx, max(q4[0], q4[1])), max(q4[2], q4[3]));
+                            umn = min(min(umn, min(u0, u1)), min(u2, u3));
+                            umx = max(max(umx, max(u0, u1)), max(u2, u3));
+                        }
+                    }
+                    m12[4 * k] = v3_enc_max(mx); m12[4 * k + 1] = v3_enc_min(mn); m12[4 * k + 2] = umx; m12[4 * k + 3] = ~umn;
+                }
+            };
+            if (!partial) quantize(std::true_type{}); else quantize(std::false_type{});
+            uint32_t o3[3];
+            wave_max12_u32(m12, o3);
+            // a wave whose least pixel index is <= 0 may hold a quotient in the denormal range, where the float64 multiply can
+            // round differently from the IEEE division: reload the floats and redo that component exactly (rare)
+            {
+                // lane 1 holds the statistics 6..8 = (k = 1: umx, ~umn), (k = 2: max); the minima are values 1, 5, 9: lanes 0 (slot 1), 2 (slot 2 of 3..5 -> value 5), 3 (slot 0 of 9..11)
+                const int32_t mn0 = v3_dec_min((uint32_t)__shfl((int)o3[1], 0)), mn1 = v3_dec_min((uint32_t)__shfl((int)o3[2], 2)), mn2 = v3_dec_min((uint32_t)__shfl((int)o3[0], 3));
+                redo[0] = mn0 <= 0; redo[1] = mn1 <= 0; redo[2] = mn2 <= 0;
+            }
+            if (__builtin_expect(redo[0] || redo[1] || redo[2], 0)) {
+                // (the floats are gone -- they became Q --: fetch them again; everything here is waited for before it is left)
+                const uint32_t b0 = origin(nsc);
+                const float* gp = a.vec + 3 * (int64_t)b0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (!redo[k]) continue;
+                    int32_t mn = 0x7fffffff, mx = (int32_t)0x80000000;
+                    uint32_t umn = 0xffffffffu, umx = 0u;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const uint32_t off = group_off(nt * kVTile + 4 * (uint32_t)(opaque_tid() + 256 * g));
+                        if (off != kV3Oob) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float x = *(const MNW_GLOBAL_SC float*)(gp + (off >> 2) + 3 * c + k);
+                                const float rq = __fdiv_rn(__fsub_rn(x, qlow[k]), qdx[k]);
+                                const int32_t q = cvt_floor_i32(rq);
+                                Q[k][4 * g + c] = (uint32_t)q;
+                                const uint32_t u = (uint32_t)q - qh[k];
+                                mn = min(mn, q); mx = max(mx, q); umn = min(umn, u); umx = max(umx, u);
+                            }
+                        }
+                    }
+                    m12[4 * k] = v3_enc_max(mx); m12[4 * k + 1] = v3_enc_min(mn); m12[4 * k + 2] = umx; m12[4 * k + 3] = ~umn;
+                }
+                wave_max12_u32(m12, o3);
+            }
             if (l < 4) {
                 const int base = 6 * (l & 1) + 3 * (l >> 1);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) red[base + i][wv] = o3[i];
             }
-            const int bad = __any(nonfinite);
+            const int bad = __any(__builtin_amdgcn_classf(nansum, 0x203));               // a NaN or an infinity among the quotients
             if (l == 0) redbad[wv] = bad;
         }
-        MNW_STAMP(0)      // wait for NEW's loads (the records arrive before them), lane statistics, wave reductions
-        // waves 0..2: fold both halves (wave k: block k's group records, and component k's group duty)
-        uint32_t gv[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
-        uint32_t gfl = 0, dfl = 0;                         // bit 0: a record is missing, bit 1: a member was not finite (lower / upper half)
-        if (wv < 3) {
-            uint32_t missing = 0, bad = 0;
-            uint32_t vl[4] = {0, 0, 0, 0};
-            if (mine) {
-                const uint32_t tg[4] = {ga.y, ga.w, gb.y, gb.w};
-                vl[0] = ga.x; vl[1] = ga.z; vl[2] = gb.x; vl[3] = gb.z;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { missing |= (tg[k] & ~kRecBad) != gen; bad |= tg[k] & kRecBad; }
+        MNW_STAMP(4)          // wait for the floats, quantize, statistics, wave reduction
+        lds_barrier();                                   // the planes and the statistics are in LDS
+        // ---- 5. wave 3 publishes the item's three records (lanes 0..11: component l / 4, word l % 4); a NaN flags all three blocks
+        {
+            uint32_t off = kV3Oob;
+            u32x2 w64 = {0, 0};
+            const int lp = opaque_tid() & 63;
+            if (wv == 3 && have_n && lp < 12 && (int64_t)nit != ra.drop_item) {
+                const int k = lp >> 2, w4 = lp & 3;
+                const uint32_t v = max(max(red[lp][0], red[lp][1]), max(red[lp][2], red[lp][3]));
+                const int bd = redbad[0] | redbad[1] | redbad[2] | redbad[3];
+                w64.x = v; w64.y = gen | (bd ? kRecBad : 0u);
+                off = (((uint32_t)k * s3 + nsc) * T + nt) * 32u + 8u * (uint32_t)w4;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) half_wave_max_dpp(vl[k], gv[k], dv[k]);
-            const uint64_t mm = __ballot(missing != 0), bm = __ballot(bad != 0);
-            gfl = ((uint32_t)mm ? 1u : 0u) | ((uint32_t)bm ? 2u : 0u);
-            dfl = ((uint32_t)(mm >> 32) ? 1u : 0u) | ((uint32_t)(bm >> 32) ? 2u : 0u);
-            if (have_old) {
-                if (__builtin_expect((gfl & 1u) && !(MNW_V3_DIAG & 1), 0)) {
-                    // a group record was not there yet (its group more than a trip behind): poll the row
-                    uint32_t spins = 0;
-                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-                    const ItemRec* row = ra.grecs + ((int64_t)(wv * s3 + osc) * R + ot / kVGroup) * R;
-                    for (;;) {
-                        uint64_t w[4] = {0, 0, 0, 0};
-                        uint32_t ms = 0, bd = 0;
-                        if (l < (int)R) {
-                            load_rec_sc1(row + l, w);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) { const uint32_t tag = (uint32_t)(w[k] >> 32); ms |= (tag & ~kRecBad) != gen; bd |= tag & kRecBad; }
-                        }
-                        if (!__any(ms)) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) gv[k] = wave_max_dpp(l < (int)R ? (uint32_t)w[k] : 0u);
-                            gfl = __any(bd) ? 2u : 0u;
-                            break;
-                        }
-                        if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; break; }
-                    }
-                }
-                if (l < 5) swp[wv][l] = l == 0 ? gv[0] : l == 1 ? gv[1] : l == 2 ? gv[2] : l == 3 ? gv[3] : gfl;
-            }
+            __builtin_amdgcn_raw_buffer_store_b64(w64, rec_r, (int)off, 0, 16);           // sc1
         }
-        lds_barrier();
-        // ---- 3. publish NEW's three records (lanes 0..11: component tid / 4, word tid % 4)
-        if (have_new && tid < 12 && sc * T + t != (uint32_t)ra.drop_item) {
-            const int k = tid >> 2, w4 = tid & 3;
-            // word 0: max, 1: min, 2: max below the split, 3: min at / above it (red rows 4k + {1, 0, 2, 3})
-            const int row = 4 * k + (w4 == 0 ? 1 : w4 == 1 ? 0 : w4);
-            float v = fmaxf(fmaxf(red[row][0], red[row][1]), fmaxf(red[row][2], red[row][3]));
-            const int bd = redbad[0] | redbad[1] | redbad[2] | redbad[3];
-            uint32_t val;
-            if (w4 == 0) val = bd ? 0 : fkey(v);
-            else if (w4 == 1) val = bd ? 0 : (uint32_t)~fkey(-v);
-            else if (w4 == 2) val = (bd || v == -INFINITY) ? 0 : fkey(v);
-            else val = (bd || v == -INFINITY) ? 0 : (uint32_t)~fkey(-v);
-            const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (bd ? kRecBad : 0u)) << 32);
-            __hip_atomic_store(&ra.recs[(int64_t)(k * s3 + sc) * T + t].g[w4], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        MNW_STAMP(1)      // record fold (waits for the record loads) + barrier + publish
-        uint32_t qq[kGroup];
-        if (wv == 3) {
-            // ---- 4a. wave 3: the three descriptors of OLD's sub-cell, lanes 0..11
-            if (have_old && l < 12) {
-                const int c = l >> 2;
-                const uint64_t g = desc3_from_sweep_f32(jpar[c], (int64_t)c * s3 + osc, swp[c][l & 3], (swp[c][4] & 2u) != 0, meta, ot == 0);
-                if ((l & 3) == 0) gran_s[c] = g;
-            }
-        } else {
-            if (have_mid) quantize_mid();                 // (wave 3 does its share after the descriptors, while the others pack)
-            if (have_mid && !(MNW_V3_DIAG & 2)) {
-                // ---- 4b. waves 0..2: the group duty of MIDDLE for this component: publish the fold of its group's item records
-                const int member = (int)(mt - mfirst);
-                if (__builtin_expect((dfl & 1u) && !(MNW_V3_DIAG & 4), 0)) {
-                    // an item record of the group was not there yet (a neighbour more than a trip behind): poll
-                    uint32_t spins = 0;
-                    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
-                    const ItemRec* r0 = ra.recs + (int64_t)(wv * s3 + msc) * T + mfirst;
-                    for (;;) {
-                        uint64_t w[4] = {0, 0, 0, 0};
-                        uint32_t ms = 0, bd = 0;
-                        if (l < mcnt) {
-                            load_rec_sc1(r0 + l, w);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) { const uint32_t tag = (uint32_t)(w[k] >> 32); ms |= (tag & ~kRecBad) != gen; bd |= tag & kRecBad; }
-                        }
-                        if (!__any(ms)) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) dv[k] = wave_max_dpp(l < mcnt ? (uint32_t)w[k] : 0u);
-                            dfl = __any(bd) ? 2u : 0u;
-                            break;
-                        }
-                        if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { dfl = 1u; if (l == 0) abort_s = 1; break; }
-                    }
-                }
-                if (!(dfl & 1u) || (MNW_V3_DIAG & 4))
-                    publish_group_rec(ra.grecs + (int64_t)(wv * s3 + msc) * R * R, (int)R, (int)mgrp, member, mcnt,
-                                      dv[0], dv[1], dv[2], dv[3], (dfl & 2u) != 0, gen);
-            }
-            if (have_old) {
-                // the lane's 32 pixel indices of OLD's plane, while wave 3 works out the descriptors
-                const uint32_t* plane = lds + wv * kVPlane;
-#pragma unroll
-                for (int k8 = 0; k8 < kGroup / 4; ++k8) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(plane + l * kStride32 + 4 * k8);
-                    qq[4 * k8] = rr.x; qq[4 * k8 + 1] = rr.y; qq[4 * k8 + 2] = rr.z; qq[4 * k8 + 3] = rr.w;
-                }
-            }
-        }
-        MNW_STAMP(2)      // group duty, LDS read | descriptors
-        lds_barrier();                                   // descriptors visible; every lane holds its group: the planes can be overwritten
-        if (abort_s) break;
-        if (wv == 3 && have_mid) quantize_mid();
-        if (wv < 3 && have_old) {
-            // ---- 4c. re-base, pack, store
-            const Vec3JobPar& jp = jpar[wv];
-            const Desc dw = gran_decode(gran_s[wv], jp.n);
-            if (__builtin_amdgcn_readfirstlane(dw.status == 0 && dw.bits != 0)) {
-                const uint32_t bw = (uint32_t)__builtin_amdgcn_readfirstlane(dw.bits);
-                const uint32_t iminw = (uint32_t)(int32_t)dw.imin;
-                const uint32_t wrapw = (jp.periodic == 1 && dw.pmin == dw.imin) ? (uint32_t)jp.pixels : 0u;
-                uint32_t* plane = lds + wv * kVPlane;
-                const int64_t e0 = (int64_t)ot * kVTile + kGroup * l;
-                if (wrapw == 0) {
-#pragma unroll
-                    for (int i = 0; i < kGroup; ++i) qq[i] -= iminw;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kGroup; ++i) { const uint32_t r2 = qq[i] - iminw; qq[i] = min(r2, r2 + wrapw); }
-                }
-                if (e0 + kGroup > jp.n) {
-#pragma unroll
-                    for (int i = 0; i < kGroup; ++i) if (e0 + i >= jp.n) qq[i] = 0;
-                }
-                pack_group32_switch(qq, bw, plane + l * bw);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                MNW_STAMP(3)      // re-base, pack
-                const int64_t byte0 = (int64_t)ot * (kVTile / 8) * bw;
-                int64_t nbytes_t = (int64_t)(kVTile / 8) * bw;
-                if (byte0 + nbytes_t > dw.nbytes) nbytes_t = dw.nbytes - byte0;
-                uint8_t* dst = (uint8_t*)jobs[(int64_t)wv * s3 + osc].dst;
-                const int full = (int)(nbytes_t >> 4);
-                for (int c = l; c < full; c += 64)
-                    stg<u32x4>(dst + byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(plane + 4 * c));
-                const int rem = (int)(nbytes_t & 15);
-                if (l < rem) {
-                    const uint32_t w = plane[4 * full + (l >> 2)];
-                    stg<uint8_t>(dst + byte0 + 16 * (int64_t)full + l, (uint8_t)(w >> (8 * (l & 3))));
-                }
-            }
-        }
-        lds_barrier();                                   // planes free
-        MNW_STAMP(4)      // stores issued + barrier
-        // ---- 5. next trip's record loads; MIDDLE's pixel indices -> LDS; NEW becomes MIDDLE; start the next item
-        issue_records(have_mid, msc, mt, have_new, sc, t);
-        if (have_mid) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint32_t e = 4 * (tid + 256 * r);                // element of the vtile
-                const Vec3Group& g = gm[r];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) *reinterpret_cast<sc_f32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = g.comp(k);
-            }
-        }
-        if (have_new) {
-            // (the copy is pinned here, ahead of the loads: left to the compiler it becomes a copy at the loop's back edge, the
-            // loads then go to temporaries and are WAITED FOR there to be moved into NEW's registers)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                gm[r] = gn[r];
-                asm volatile("" : "+v"(gm[r].u), "+v"(gm[r].v), "+v"(gm[r].w));
-            }
-            if (have_next) issue(nsc, nt);
-        }
-        MNW_STAMP(5)      // quantize + park MIDDLE, next loads issued
-        have_old = have_mid; osc = msc; ot = mt;
-        have_mid = have_new; msc = sc; mt = t;
-        sc = nsc; t = nt;
-        have_new = have_next;
+        // ---- 6. requests of the next trip: the descriptor of the sub-cell now parked (a sweeper publishes it once the sub-cell's last
+        // record is out; a request that comes back empty costs polled round trips at the start of the next trip, so it is made as
+        // late as possible), then the next item's floats
+        issue_desc(DEEP ? have_p : have_q, DEEP ? psc : qsc);
+        issue_floats(have_next, nsc2, nt2);
+        MNW_STAMP(5)          // barrier, publish (and the sweep duty, once per sub-cell), requests
+        if (DEEP) { have_o = have_p; osc = psc; ot = pt; have_p = have_q; psc = qsc; pt = qt; }
+        else { have_o = have_q; osc = qsc; ot = qt; }
+        have_q = have_n; qsc = nsc; qt = nt;
+        nit = nit2; nsc = nsc2; nt = nt2;
+        have_n = have_next;
     }
     MNW_STAMP_FLUSH
+    MNW_V3_COUNT_FLUSH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,12 +1067,6 @@ __device__ __forceinline__ sc_f32x4 v3_dequant4(const V3Dec& d, const uint32_t* 
 constexpr int kV3ImgDw = 64 * 12 + 64;          // dwords per wave: the image and the 64 grid offsets
 constexpr uint32_t kV3NoStore = 0xfffff800u;    // a grid offset beyond every buffer's range (they end below 0xfffff001), also with 32 added
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t v3_rsrc(const void* base, uint32_t bytes) {
-    const uint64_t p = (uint64_t)base;
-    const uint64_t pu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(p >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
 
 // The aligned 64-bit words that hold vtile t of a stream -> registers (lane i of the workgroup takes words i, i + 256, ...);
 // words past the stream's end read as zero (they only feed elements beyond n, which are never stored).
@@ -1172,41 +1234,40 @@ void launch_pack_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file,
     const Vec3Args a = make_vec3_args(vec, n_file, sub_cells);
     hipLaunchKernelGGL(k_pack_vec3, dim3(grid), dim3(256), 0, s, a, jobs, stats, meta);
 }
-// single-read vectors encode.  recs: 3 s3 T item records, then 3 s3 R R group records (R = ceil(T / kVGroup)).
+// single-read vectors encode.  recs (in units of ItemRec): 3 s3 T item records, then 3 s3 descriptor records of 16 bytes
 int64_t vec3_reg_recs(int64_t n_file, int64_t sub_cells) {
     const SubcellGeom g = make_geom(n_file, sub_cells);
-    const int64_t s3 = sub_cells * sub_cells * sub_cells, T = (g.n_sub3 + kVTile - 1) / kVTile, R = (T + kVGroup - 1) / kVGroup;
-    return 3 * s3 * (T + R * R);
+    const int64_t s3 = sub_cells * sub_cells * sub_cells, T = (g.n_sub3 + kVTile - 1) / kVTile;
+    return 3 * s3 * T + (3 * s3 + 1) / 2;
 }
-int64_t vec3_reg_max_tiles_per_block() { return 32 * kVGroup; }           // R <= 32: one group record per lane of a half wave
-// geometries k_encode_reg_vec3 takes: its multiply-high divisions need 8 <= n_sub <= 128 and sub_cells <= 32, its record
-// offsets fewer than 2^26 records
+int vec3_reg_sweepers() { return 8; }                                      // workgroups of the grid that hold no items
+int64_t vec3_reg_max_tiles_per_block() { return 1ll << 20; }               // (the sweep takes any T; what bounds T is the resident grid)
+// geometries k_encode_reg_vec3 takes: its multiply-high divisions need 8 <= n_sub < 512, n_sub a multiple of four, its grid
+// offsets a sub-cell's span of the grid below 2^32 bytes, its record offsets fewer than 2^26 records
 bool vec3_reg_geometry_ok(int64_t n_file, int64_t sub_cells) {
-    if (sub_cells < 1 || sub_cells > 32 || n_file % sub_cells) return false;
+    if (sub_cells < 1 || n_file % sub_cells) return false;
     const int64_t n_sub = n_file / sub_cells;
-    if (n_sub < 8 || n_sub > 128 || n_sub % 4 || n_file % 4) return false;
+    if (n_sub < 8 || n_sub >= 512 || n_sub % 4 || n_file % 4) return false;
+    if (n_sub * n_file * n_file * 12 >= 0xfff00000ll) return false;
     return vec3_reg_recs(n_file, sub_cells) < (1ll << 26);
 }
-int encode_reg_vec3_blocks_per_cu() {
+int encode_reg_vec3_blocks_per_cu(bool deep) {
+    if (!deep) { int m = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_encode_reg_vec3<false>, 256, 0) != hipSuccess) return 0; return m; }
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_vec3, 256, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_vec3<true>, 256, 0) != hipSuccess) return 0;
     return n;
 }
 void launch_encode_reg_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, void* recs,
-                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item) {
+                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item, int weighted, bool deep) {
     Vec3RegArgs ra;
     ra.a = make_vec3_args(vec, n_file, sub_cells);
-    ra.R = (ra.a.tiles_per_sc + kVGroup - 1) / kVGroup;
     ra.recs = (ItemRec*)recs;
-    ra.grecs = ra.recs + (size_t)3 * ra.a.s3 * ra.a.tiles_per_sc;
     ra.gen = gen; ra.abort_flag = abort_flag; ra.abort_host = abort_host; ra.drop_item = drop_item;
-    // multiply-high division: exact for x d < 2^32; here x < n_sub^3 / 4 with d = n_sub / 4, and x < n_sub^2 with d = n_sub
-    // (the host only sends n_sub <= 128 here: vec3_reg_max_tiles_per_block)
-    ra.m_row = (uint32_t)((1ull << 32) / (ra.a.gm.n_sub / 4)) + 1u;
-    ra.m_nsub = (uint32_t)((1ull << 32) / ra.a.gm.n_sub) + 1u;
-    ra.m_s = sub_cells == 1 ? 0u : (uint32_t)((1ull << 32) / sub_cells) + 1u;              // (one sub-cell: every quotient is 0)
-    ra.m_s2 = sub_cells == 1 ? 0u : (uint32_t)((1ull << 32) / (sub_cells * sub_cells)) + 1u;
-    hipLaunchKernelGGL(k_encode_reg_vec3, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
+    ra.n_sweepers = (uint32_t)vec3_reg_sweepers();
+    ra.weighted = ((grid - (int)ra.n_sweepers) % 4 == 0 && weighted >= 0 && weighted <= kRoundTables) ? weighted : 0;
+    ra.m_T = ra.a.tiles_per_sc > 1 ? (uint32_t)((1ull << 32) / ra.a.tiles_per_sc) + 1u : 0u;
+    if (deep) hipLaunchKernelGGL(k_encode_reg_vec3<true>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
+    else hipLaunchKernelGGL(k_encode_reg_vec3<false>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
 }
 int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
     const int64_t n_sub = n_file / sub_cells, n3 = n_sub * n_sub * n_sub;

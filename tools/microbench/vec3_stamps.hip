@@ -1,5 +1,5 @@
 // Diagnostic (not product): k_encode_reg_vec3 on a C4-shaped file cell -- kernel time and per-phase cycle sums of wave 0.
-//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off [-DMNW_V3_DIAG=..] vec3_stamps.hip -o vec3_stamps && ./vec3_stamps [n_file sub_cells grid]
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off vec3_stamps.hip -o vec3_stamps && ./vec3_stamps [n_file sub_cells grid]
 #define MNW_STAMPS 1
 #include "../../minnow_amd/csrc/mnw_kernels.hip"
 #include <cstdio>
@@ -21,6 +21,8 @@ __global__ void k_fill(float* x, long n, int nf) {
 int main(int argc, char** argv) {
     const long nf = argc > 1 ? atol(argv[1]) : 500, S = argc > 2 ? atol(argv[2]) : 5;
     int grid = argc > 3 ? atoi(argv[3]) : 1024;
+    const int weighted = argc > 4 ? atoi(argv[4]) : 0;
+    const bool deep = argc > 5 ? atoi(argv[5]) != 0 : true;
     const long n = nf * nf * nf, s3 = S * S * S, nsub = nf / S, nsub3 = nsub * nsub * nsub;
     float* x; uint8_t* out; unsigned long long* sb;
     const long slot = (4 * nsub3 + 15) / 16 * 16;
@@ -41,23 +43,28 @@ int main(int argc, char** argv) {
     CHK(hipMemcpy(dj, hj.data(), sizeof(DevJob) * hj.size(), hipMemcpyHostToDevice)); CHK(hipMemset(recs, 0, sizeof(ItemRec) * nrec)); CHK(hipMemset(ab, 0, 128));
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     uint32_t gen = 1;
-    auto launch = [&]() { launch_encode_reg_vec3(0, grid, x, nf, S, dj, recs, gen++, ab, ab + 8, dm, -1); };
+    auto launch = [&]() { launch_encode_reg_vec3(0, grid, x, nf, S, dj, recs, gen++, ab, ab + 8, dm, -1, weighted, deep); };
     for (int r = 0; r < 3; ++r) launch();
+    unsigned long long* vd; CHK(hipMalloc(&vd, 8 * 8 * 4096)); CHK(hipMemset(vd, 0, 8 * 8 * 4096));
     CHK(hipDeviceSynchronize()); CHK(hipMemset(sb, 0, 8 * 8 * 4096));
+    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_v3_diag), &vd, sizeof(vd)));
     CHK(hipDeviceSynchronize()); CHK(hipEventRecord(a)); launch(); CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
     float ms; CHK(hipEventElapsedTime(&ms, a, b));
     std::vector<unsigned long long> h(8 * grid); CHK(hipMemcpy(h.data(), sb, 8 * 8 * grid, hipMemcpyDeviceToHost));
     Meta m0; CHK(hipMemcpy(&m0, dm, sizeof m0, hipMemcpyDeviceToHost)); uint32_t abv; CHK(hipMemcpy(&abv, ab, 4, hipMemcpyDeviceToHost));
-    const char* names[6] = {"loads wait+lane stats", "record fold+barrier+publish", "group duty", "descriptor+read+pack", "store+barrier", "park+issue next"};
+    const char* names[6] = {"descriptor wait", "plane read+re-base+pack+stores", "barrier 1", "park", "floats wait+quantize+statistics", "requests+barrier 2+publish(+duty)"};
     double cyc = 0, rt = 0; for (int w = 0; w < grid; ++w) { cyc += h[w * 8 + 6]; rt += h[w * 8 + 7]; }
     const double ghz = cyc / rt * 0.1, items = (double)vt;
-    printf("n_file=%ld sub_cells=%ld vtiles=%ld grid=%d items/WG=%.1f diag=%d: kernel %.1f us (stamped build) bits=%ld abort=%u\n", nf, S, vt, grid, items / grid, MNW_V3_DIAG, ms * 1e3,
+    printf("n_file=%ld sub_cells=%ld vtiles=%ld grid=%d weighted=%d deep=%d items/WG=%.1f: kernel %.1f us (stamped build) bits=%ld abort=%u\n", nf, S, vt, grid, weighted, (int)deep, items / grid, ms * 1e3,
            (long)m0.bits, abv);
     printf("  workgroup lifetime mean %.2f us, shader clock %.2f GHz\n", rt / grid / 100.0, ghz);
     for (int i = 0; i < 6; ++i) {
         double s2 = 0; for (int w = 0; w < grid; ++w) s2 += h[w * 8 + i];
         printf("  %-28s %.2f us per WG = %.2f us per item\n", names[i], s2 / grid / ghz / 1e3, s2 / grid / ghz / 1e3 / (items / grid));
     }
+    { std::vector<unsigned long long> hc(8 * grid); CHK(hipMemcpy(hc.data(), vd, 8 * 8 * grid, hipMemcpyDeviceToHost));
+      unsigned long long dg[8] = {0}; for (int w = 0; w < grid; ++w) for (int i = 0; i < 8; ++i) dg[i] += hc[w * 8 + i];
+      printf("  this launch, wave 0 of every workgroup: descriptor uses %llu, of which not there yet %llu, poll iterations %llu; sweeps %llu, sweep iterations %llu\n", dg[0], dg[1], dg[2], dg[3], dg[4]); }
     // spread of the workgroup lifetimes by quarter of the grid
     for (int q = 0; q < 4; ++q) { double s2 = 0; for (int w = q * grid / 4; w < (q + 1) * grid / 4; ++w) s2 += h[w * 8 + 7]; printf("  quarter %d: lifetime %.1f us\n", q, s2 / (grid / 4) / 100.0); }
     return 0;
