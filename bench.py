@@ -15,8 +15,10 @@ block sizes) and one minp file cell of configs[3] (500^3 particles, 375 blocks p
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The column is cut into blocks
 and the blocks are dealt to the ranks in contiguous ranges (minnow_amd.shard.shard_range; a block's (min, bits,
 bytes) depends on that block only, go/group.go:242-255, 312-327): no data-path collective.  Weak scaling (the
-default): the global column has N x 1e9 particles, every rank owns 1e9 of them; --strong: the global column has
-1e9 particles whatever N is.  After the timed steps the ranks' (min, bits, nbytes) are gathered in block order and
+default): the global column has N x 1e9 particles, cut into blocks and the BLOCKS dealt evenly -- a rank owns 954
+or 953 blocks of 2^20 (1,000,341,504 or 999,292,928 particles), the last rank the ragged last block; every rank's
+own element count is reported (`per_rank`) and the per-GPU fractions are computed from the slowest rank's.
+--strong: the global column has 1e9 particles whatever N is.  After the timed steps the ranks' (min, bits, nbytes) are gathered in block order and
 prefix-summed into the file offsets of go/block_index.go:16-35 -- a few integers per block, the only thing that
 ever crosses ranks.  `value` is the whole-job aggregate; rank 0 prints ONE JSON line.
 """
@@ -36,7 +38,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LOW, HIGH, DX = 0.0, 250.0, 0.001
-PROFILE_TAG = "r02"             # profiles/<tag>/pmc_traffic.json holds the PMC traffic of this workload
+PROFILE_TAG = "r03"             # profiles/<tag>/pmc_traffic.json holds the PMC traffic of this workload
 
 
 def parse():
@@ -97,11 +99,28 @@ def host_cores():
     return logical, (len(phys) or None)
 
 
-def cpu_baseline(mnw_pixels, n_threads, target_s=12.0):
-    """The oracle's LITERAL byte-wise restatement of go/bit + group.go (kind "port": the Go
-    reference cannot be built in this image) timed on this host's cores, on a bounded sample of the
-    same workload: each thread encodes and decodes its own blocks of 2^22 elements.  The number of
-    blocks per thread is calibrated so that the sample takes about `target_s` seconds."""
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's quota if there is one (the GPU boxes give a job a share of the
+    host), else the affinity mask"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            return max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(mnw_pixels, target_s=5.0):
+    """The oracle's LITERAL byte-wise restatement of go/bit + group.go (kind "port": the Go reference cannot be built
+    in this image) timed on this host, on a bounded sample of the same workload: every thread encodes and decodes its
+    own blocks of 2^22 elements.  Two figures, as BASELINE.md section 3 asks: ONE thread, and ALL the cores this job
+    may use (the host's physical cores, capped by the job's CPU quota: a GPU box gives a one-GPU job a share of the
+    host, not the host).  About `target_s` seconds each."""
     from oracle import oracle as orc
 
     orc.build()
@@ -121,26 +140,52 @@ def cpu_baseline(mnw_pixels, n_threads, target_s=12.0):
     t_one = time.perf_counter() - t0
     per_thread = max(2, min(200, int(target_s / max(t_one, 1e-3))))
 
-    def work():
-        for _ in range(per_thread):
-            one()
+    def run(n_threads):
+        def work():
+            for _ in range(per_thread):
+                one()
 
-    threads = [threading.Thread(target=work) for _ in range(n_threads)]
-    t0 = time.perf_counter()
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t0
-    total_bytes = 4.0 * blk * per_thread * n_threads
+        threads = [threading.Thread(target=work) for _ in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+        return 4.0 * blk * per_thread * n_threads / dt / 1e9, dt
+
     logical, phys = host_cores()
+    quota = cpu_quota()
+    n_all = max(1, min(phys or logical, quota, 256))
+    v1, dt1 = run(1)
+    va, dta = run(n_all)
     return {
-        "value": total_bytes / dt / 1e9, "unit": "GB/s", "cores": n_threads, "kind": "port",
-        "host_logical_cpus": logical, "host_physical_cores": phys,
-        "sample": "%d threads (host: %d logical CPUs, %s physical cores) x %d blocks of 2^22 float32 (same Gaussian column "
-                  "shape), encode+decode with the literal byte-wise restatement of go/bit + group.go, %.1f s"
-                  % (n_threads, logical, phys if phys else "?", per_thread, dt),
+        "value": va, "unit": "GB/s", "cores": n_all, "threads": n_all, "kind": "port",
+        "one_thread": {"value": v1, "unit": "GB/s", "cores": 1, "threads": 1},
+        "host_logical_cpus": logical, "host_physical_cores": phys, "cpu_quota": quota,
+        "sample": "the literal byte-wise restatement of go/bit + group.go, encode+decode of blocks of 2^22 float32 (the same "
+                  "Gaussian column shape): 1 thread x %d blocks in %.1f s, then %d threads (host: %d logical CPUs, %s physical "
+                  "cores; this job may use %d) x %d blocks each in %.1f s"
+                  % (per_thread, dt1, n_all, logical, phys if phys else "?", quota, per_thread, dta),
     }
+
+
+def stream_ceiling():
+    """What a bare stream of the kernels' traffic mix reaches on THIS GPU (tools/microbench/rw_mix: one 16-byte access per
+    thread, no arithmetic), run as a child process before the timed steps.  None if the binary is not there."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tools", "microbench", "rw_mix")
+    if not os.path.exists(exe):
+        return None
+    try:
+        o = subprocess.run([exe, "4", "json"], capture_output=True, text=True, timeout=120)
+        for line in o.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
 
 
 def run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, steps, warmup, timing, block0=0, across_ranks=True, cdev=None):
@@ -347,7 +392,7 @@ def minp_leg(mnw, ctx, device, reps, timing):
     d = torch.minimum(d, L - d)
     assert float(d.max()) <= dx * 1.01 + 1e-4
     alg = 12.0 * n + pb
-    enc_us = sum(v for k, v in kt.items() if k in ("k_reduce_vec3", "k_pack_vec3", "k_encode_vec3", "k_subcell_gather", "k_encode_reg_f32", "k_reduce_f32", "k_pack_f32"))
+    enc_us = sum(v for k, v in kt.items() if k in ("k_encode_reg_vec3", "k_reduce_vec3", "k_pack_vec3", "k_subcell_gather", "k_encode_reg_f32", "k_reduce_f32", "k_pack_f32"))
     dec_us = sum(v for k, v in kt.items() if k in ("k_unpack_vec3", "k_unpack_f32", "k_subcell_scatter"))
     rec = {"n_file": nf, "sub_cells": S, "particles": n, "blocks": nb, "bits": sorted(set(m.bits for m in metas)),
            "ms_per_step": dt * 1e3, "value": 12.0 * n / dt / 1e9, "unit": "GB/s of input (12 B per particle), encode + decode",
@@ -504,6 +549,7 @@ def main():
     if a.two_pass:
         ctx.set_option("single_read", 0)
     timing = not a.no_kernel_timing
+    ceiling = stream_ceiling() if (world == 1 and rank == 0) else None      # (a child process on this GPU, before anything is timed)
 
     r = run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, a.steps, a.warmup, timing, block0=b_lo, cdev=cdev)
 
@@ -535,6 +581,20 @@ def main():
                                  across_ranks=False)
                 extra["column_1e8_blocks_2p%d" % (a.alt_block.bit_length() - 1)] = leg_record(
                     rs2, timing, "configs[1] in blocks of %d elements (SURVEY.md 8d C2's default block)" % a.alt_block)
+        if world == 1:
+            # one GPU's share of --strong at 8 GPUs (1.25e8 particles of the column), timed here: the 8-GPU speed-up it projects,
+            # while no 8-GPU node has measured the real one
+            nsh = a.particles // 8
+            if 0 < nsh < N:
+                rsh = run_config(mnw, shard, ctx, x, y, device, dist, nsh, B, pixels, min(a.steps, 20), 3, timing, across_ranks=False)
+                rec = leg_record(rsh, timing, "one GPU's share of `--strong --gpus 8`: %d particles of the column, blocks of %d" % (nsh, B))
+                rec["projected_speedup_8_gpus"] = (r["dt"] / r["steps"]) / (rsh["dt"] / rsh["steps"])
+                rec["projection"] = "ms_per_step of the whole column on this GPU / ms_per_step of an eighth of it on this GPU (no exchange between ranks: blocks are independent)"
+                extra["strong_projection"] = rec
+            # SURVEY 8d C2's third block size: the whole column as ONE block (too large to be held on chip: reduce + pack, two reads)
+            rw = run_config(mnw, shard, ctx, x, y, device, dist, N, N, pixels, 3, 1, timing, across_ranks=False)
+            extra["column_one_block"] = leg_record(rw, timing, "the whole column as ONE block of %d elements (SURVEY.md 8d C2 'whole column'): "
+                                                   "k_reduce_f32 + k_pack_f32, the block is read twice" % N)
         if not a.no_minp:
             del y
             torch.cuda.empty_cache()
@@ -559,6 +619,16 @@ def main():
         print("bench.py: rank %d: the single-read launch gave up %d time(s) -- something else was running on this GPU; "
               "the batch was redone by the two-launch path (correct, slower)" % (rank, counters["single_read_aborts"]), file=sys.stderr)
 
+    enc_r, dec_r, _ = rooflines(r, timing)
+    mine = {"rank": rank, "particles": N, "blocks": r["nblk"], "ms_per_step_own_clock": r["t_enc"] * 1e3 + r["t_dec"] * 1e3,
+            "encode_kernel_us": enc_r["avg_launch_us"] if enc_r else None, "decode_kernel_us": dec_r["avg_launch_us"] if dec_r else None,
+            "encode_frac": enc_r["frac"] if enc_r else None, "decode_frac": dec_r["frac"] if dec_r else None,
+            "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None),
+            "single_read_aborts": counters["single_read_aborts"], "backoff_batches": counters.get("backoff_batches", 0)}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -589,6 +659,13 @@ def main():
                    "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)},
     }
 
+    degraded = [q for q in per_rank if q and (q["single_read_aborts"] or q["backoff_batches"])]
+    if degraded:
+        out["degraded"] = "the single-read launch gave up on rank(s) %s (%d time(s) in all; %d batches skipped it afterwards): something " \
+                          "else was running on the GPU, `value` includes the 50 ms waits and the two-launch reruns" % (
+                              [q["rank"] for q in degraded], sum(q["single_read_aborts"] for q in degraded), sum(q["backoff_batches"] for q in degraded))
+    if world > 1:
+        out["per_rank"] = per_rank
     enc, dec, kernels = rooflines(r, timing)
     if enc:
         pmc = os.path.join(ROOT, "profiles", PROFILE_TAG, "pmc_traffic.json")
@@ -606,11 +683,27 @@ def main():
         enc_us = sum(enc["avg_launch_us"].values())
         out["roofline"] = dict(dec if dec["avg_launch_us"] > enc_us else enc)
         out["roofline_encode"], out["roofline_decode"], out["kernels"] = enc, dec, kernels
+        if world > 1:
+            # the slowest rank's dominant kernel (every rank's launch averages are in `per_rank`)
+            cand = [q for q in per_rank if q and q["decode_kernel_us"]]
+            if cand:
+                slow = max(cand, key=lambda q: max(q["decode_kernel_us"], sum(q["encode_kernel_us"].values())))
+                dec_dom = slow["decode_kernel_us"] > sum(slow["encode_kernel_us"].values())
+                us = slow["decode_kernel_us"] if dec_dom else sum(slow["encode_kernel_us"].values())
+                alg = (dec if dec_dom else enc)["algorithmic_bytes_per_elt"] * slow["particles"]
+                out["roofline"] = {"bound": "hbm", "kernel": (dec if dec_dom else enc)["kernel"] + " on rank %d (the slowest)" % slow["rank"],
+                                   "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": us,
+                                   "elements_per_launch": float(slow["particles"]), "pci_bus_id": slow["pci_bus_id"]}
+        if ceiling:
+            # the same traffic mix as a bare stream on this very GPU, measured seconds before the steps: what `frac` is to be read against
+            out["roofline"]["stream_ceiling_GBps"] = ceiling.get("decode_mix_GBps" if out["roofline"]["kernel"].startswith("k_unpack") else "encode_mix_GBps")
+            enc["stream_ceiling_GBps"], dec["stream_ceiling_GBps"] = ceiling.get("encode_mix_GBps"), ceiling.get("decode_mix_GBps")
+            out["stream_ceiling"] = ceiling
     out.update(extra)
 
     if world == 1 and not a.no_cpu_baseline:
-        ncpu = os.cpu_count() or 1
-        out["cpu_baseline"] = cpu_baseline(pixels, max(1, min(16, ncpu)))
+        out["cpu_baseline"] = cpu_baseline(pixels)
 
     print(json.dumps(out))
     if dist is not None:

@@ -67,6 +67,64 @@ struct DevBuf {
         return static_cast<uint8_t*>(p);
     }
 };
+// One thread that performs the file writes of the blocks in order, so that the writes of block b overlap the upload,
+// parse and encode of block b+1 (minnow::Writer itself is single threaded: only this thread touches it between
+// Header/Geometry and Close).  `done` callbacks run on the posting thread, in drain() / post().
+struct FileWriter {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, cv_idle;
+    std::deque<std::pair<std::function<void()>, std::function<void()>>> q;
+    std::vector<std::function<void()>> finished;
+    std::exception_ptr err;
+    bool quit = false, busy = false;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || !q.empty(); });
+            if (quit || q.empty()) return;                          // (on quit the queue has been dropped)
+            auto t = std::move(q.front());
+            q.pop_front();
+            busy = true;
+            lk.unlock();
+            try { t.first(); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+            lk.lock();
+            busy = false;
+            finished.push_back(std::move(t.second));
+            cv_idle.notify_all();
+        }
+    }
+    void reap(std::unique_lock<std::mutex>& lk) {
+        std::vector<std::function<void()>> f;
+        f.swap(finished);
+        const std::exception_ptr e = err;
+        err = nullptr;
+        lk.unlock();
+        for (auto& fn : f) fn();
+        if (e) std::rethrow_exception(e);
+        lk.lock();
+    }
+    void post(std::function<void()> task, std::function<void()> done) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        cv_idle.wait(lk, [&] { return q.size() < 2; });          // at most two blocks of output in flight
+        reap(lk);
+        q.emplace_back(std::move(task), std::move(done));
+        cv.notify_all();
+    }
+    void drain() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&] { return q.empty() && !busy; });
+        reap(lk);
+    }
+    // drops what is queued, waits for the task that is running, ends the thread (idempotent; never throws)
+    void stop() noexcept {
+        { std::lock_guard<std::mutex> g(mu); quit = true; q.clear(); }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    ~FileWriter() { stop(); }
+};
 inline size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
 inline bool isFixed(int64_t t) { return t >= Int64 && t <= Float32; }
 }  // namespace detail
@@ -79,6 +137,12 @@ class Writer {
         idHeader hd{Magic, Version, fileType};
         f_->Header(hd);
     }
+    // A Writer that goes away without Close() -- a Block() that threw while the block before it was still being written, a
+    // caller that drops the object -- must not leave the file-writer thread running tasks that use f_ and cols_: queued tasks
+    // are dropped, the one that is running is waited for, and only then are the members destroyed.
+    ~Writer() { writer_.stop(); }
+    Writer(const Writer&) = delete;
+    Writer& operator=(const Writer&) = delete;
 
     // Header, minh.go:88-93
     void Header(const std::vector<std::string>& names, const std::string& text, const std::vector<Column>& cols) {
@@ -236,63 +300,7 @@ class Writer {
         if (hasHostFixed) writer_.drain();              // the task reads the caller's arrays
     }
 
-    // One thread that performs the file writes of the blocks in order, so that the writes of block b overlap the upload,
-    // parse and encode of block b+1 (minnow::Writer itself is single threaded: only this thread touches it between
-    // Header/Geometry and Close).  `done` callbacks run on the posting thread, in drain() / post().
-    struct FileWriter {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv, cv_idle;
-        std::deque<std::pair<std::function<void()>, std::function<void()>>> q;
-        std::vector<std::function<void()>> finished;
-        std::exception_ptr err;
-        bool quit = false, busy = false;
-        void run() {
-            std::unique_lock<std::mutex> lk(mu);
-            for (;;) {
-                cv.wait(lk, [&] { return quit || !q.empty(); });
-                if (q.empty()) return;
-                auto t = std::move(q.front());
-                q.pop_front();
-                busy = true;
-                lk.unlock();
-                try { t.first(); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
-                lk.lock();
-                busy = false;
-                finished.push_back(std::move(t.second));
-                cv_idle.notify_all();
-            }
-        }
-        void reap(std::unique_lock<std::mutex>& lk) {
-            std::vector<std::function<void()>> f;
-            f.swap(finished);
-            const std::exception_ptr e = err;
-            err = nullptr;
-            lk.unlock();
-            for (auto& fn : f) fn();
-            if (e) std::rethrow_exception(e);
-            lk.lock();
-        }
-        void post(std::function<void()> task, std::function<void()> done) {
-            std::unique_lock<std::mutex> lk(mu);
-            if (!th.joinable()) th = std::thread([this] { run(); });
-            cv_idle.wait(lk, [&] { return q.size() < 2; });          // at most two blocks of output in flight
-            reap(lk);
-            q.emplace_back(std::move(task), std::move(done));
-            cv.notify_all();
-        }
-        void drain() {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_idle.wait(lk, [&] { return q.empty() && !busy; });
-            reap(lk);
-        }
-        ~FileWriter() {
-            { std::lock_guard<std::mutex> g(mu); quit = true; }
-            cv.notify_all();
-            if (th.joinable()) th.join();
-        }
-    };
-    FileWriter writer_;
+    detail::FileWriter writer_;
     std::vector<std::shared_ptr<minnow::detail::RawBuf>> spare_;
 
     std::unique_ptr<minnow::Writer> f_;

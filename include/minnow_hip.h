@@ -37,6 +37,7 @@ extern "C" {
 #define MNW_E_DOMAIN     (-6)  /* width outside 0..64: max-min == 2^64-1 makes Go's PrecisionNeeded
                                   return int(-Inf) (bit.go:19-21) and the reference panic later */
 #define MNW_E_NOMEM      (-7)
+#define MNW_E_IO         (-8)  /* mnw_copy_file_to_device: pread failed or the file ends inside a requested range; errno text in mnw_last_error() */
 
 /* group-type constants of the reference (go/group.go:11-24); only these two are codec paths */
 #define MNW_INT_GROUP    10
@@ -337,7 +338,8 @@ const char *mnw_kernel_name(int kernel_id);
  * float batches took, and how often the single-read kernel gave up.  That kernel needs its whole grid co-resident
  * (mnw_set_option: single_read); when something else holds part of the GPU its bounded wait (50 ms) expires, the
  * host reruns the batch through the reduce + pack launches -- correct, but 50 ms and a 2x slower path, so a caller
- * that cares about throughput watches MNW_C_SINGLE_READ_ABORTS (bench.py asserts it is 0). */
+ * that cares about throughput watches MNW_C_SINGLE_READ_ABORTS and MNW_C_BACKOFF_BATCHES (bench.py reports both per rank and
+ * marks its JSON line "degraded" when either is not 0; tools/text_to_minh prints them in its summary). */
 #define MNW_C_SINGLE_READ_BATCHES 0  /* float batches encoded by k_encode_reg_f32 */
 #define MNW_C_SINGLE_READ_ABORTS  1  /* ... of which gave up and were rerun through reduce + pack (also counts fused launches) */
 #define MNW_C_TWO_PASS_BATCHES    2  /* float batches that went to the reduce + pack launches directly (not eligible / option) */

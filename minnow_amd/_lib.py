@@ -8,7 +8,7 @@ _LIB = os.environ.get("MNW_LIB_PATH") or os.path.join(HERE, "libminnow_hip.so") 
 MNW_OK = 0
 STATUS_NAMES = {
     0: "MNW_OK", -1: "MNW_E_ARG", -2: "MNW_E_BUFLEN", -3: "MNW_E_NOGPU", -4: "MNW_E_HIP",
-    -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM",
+    -5: "MNW_E_CAPACITY", -6: "MNW_E_DOMAIN", -7: "MNW_E_NOMEM", -8: "MNW_E_IO",
 }
 K_COUNT = 21
 C_COUNT = 8

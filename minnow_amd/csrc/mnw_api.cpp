@@ -490,7 +490,7 @@ int copy_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, const void* src, size_t b
 // n ranges of a file -> one contiguous device buffer (in the order given), through the pinned ring: the host threads pread the
 // pieces of chunk k+1 straight into a pinned buffer while the DMA engine moves chunk k -- no pageable buffer in between, no
 // page faults, no second host copy.
-int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const int64_t* file_off, const int64_t* len, const int64_t* dst_off) {
+int copy_file_h2d_impl(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const int64_t* file_off, const int64_t* len, const int64_t* dst_off) {
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (size_t)len[i];
     if (total == 0) return MNW_OK;
@@ -518,7 +518,7 @@ int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const
             }
         };
         g.pool->run((int)cur.size(), fn);
-        if (!err.empty()) return fail(c, MNW_E_ARG, ("copy_file_to_device: " + err).c_str());
+        if (!err.empty()) return fail(c, MNW_E_IO, ("copy_file_to_device: " + err).c_str());
         // one DMA per run of pieces that are contiguous in the destination as well (they are in the pinned buffer by construction)
         for (size_t k = 0; k < cur.size();) {
             size_t k2 = k + 1, run = cur[k].len;
@@ -550,7 +550,7 @@ int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const
 
 // n device -> host copies, pipelined through the pinned ring: every pinned chunk is filled by as many pieces as fit, the DMA of
 // chunk k+1 .. k+3 runs while the host threads copy chunk k out to the callers' buffers.
-int copy_d2h_batch(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const void* const* src, const int64_t* len) {
+int copy_d2h_batch_impl(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const void* const* src, const int64_t* len) {
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (size_t)len[i];
     if (total == 0) return MNW_OK;
@@ -596,7 +596,7 @@ int copy_d2h_batch(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const voi
 }
 
 // Device -> host (pageable), behind everything already enqueued on s; returns when the bytes are in `dst`.
-int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t bytes) {
+int copy_d2h_impl(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t bytes) {
     if (bytes == 0) return MNW_OK;
     if ((int64_t)bytes < c->stage_min) {
         HIPCHK(c, hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
@@ -627,6 +627,31 @@ int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t b
     }
     g.next = 0;
     return MNW_OK;
+}
+
+// An error in the middle of a staged transfer leaves DMAs in flight and the ring's bookkeeping half updated: wait for what was
+// enqueued (a synchronous entry point must not return while the destination is still being written, and the next call must not
+// refill a pinned buffer whose DMA is still running), then start the ring afresh.  The error that is reported is the first one.
+void stager_settle(mnw_ctx* c, hipStream_t s) {
+    const std::string first = c->err;
+    (void)hipStreamSynchronize(s);
+    if (c->stg.ready) { for (int b = 0; b < Stager::kBufs; ++b) c->stg.busy[b] = false; c->stg.next = 0; }
+    c->err = first;
+}
+int copy_file_h2d(mnw_ctx* c, hipStream_t s, void* dev_dst, int fd, int n, const int64_t* file_off, const int64_t* len, const int64_t* dst_off) {
+    const int rc = copy_file_h2d_impl(c, s, dev_dst, fd, n, file_off, len, dst_off);
+    if (rc) stager_settle(c, s);
+    return rc;
+}
+int copy_d2h_batch(mnw_ctx* c, hipStream_t s, int n, void* const* dst, const void* const* src, const int64_t* len) {
+    const int rc = copy_d2h_batch_impl(c, s, n, dst, src, len);
+    if (rc) stager_settle(c, s);
+    return rc;
+}
+int copy_d2h(mnw_ctx* c, hipStream_t s, void* dst, const void* dev_src, size_t bytes) {
+    const int rc = copy_d2h_impl(c, s, dst, dev_src, bytes);
+    if (rc) stager_settle(c, s);
+    return rc;
 }
 
 // Wait for a stream whose work is expected to finish within microseconds: poll before blocking (a blocking
@@ -1107,6 +1132,7 @@ const char* mnw_strerror(int status) {
         case MNW_E_CAPACITY: return "packed stream does not fit the output capacity";
         case MNW_E_DOMAIN: return "bit width outside 0..64 (max-min == 2^64-1)";
         case MNW_E_NOMEM: return "out of memory";
+        case MNW_E_IO: return "file I/O error (read failed or the file is shorter than the ranges asked for)";
         default: return "unknown status";
     }
 }

@@ -1506,6 +1506,9 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
             const uint64_t w64 = (uint64_t)val | ((uint64_t)(gen | (bd ? kRecBad : 0u)) << 32);
             __hip_atomic_store(&recs[sit].g[tid], w64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // (first trip only: nothing below separates these reads of red[] from the next trip's statistics of the waves that skip
+        // step 3 -- later trips have step 3's barriers in between)
+        if (!have_prev) lds_barrier();
         MNW_STAMP(1)      // reductions + records folded + barrier + publish
 
         if (have_prev) {
@@ -1855,6 +1858,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
             const uint32_t half = (tid & 1) ? (uint32_t)v64 : (uint32_t)(v64 >> 32);
             __hip_atomic_store(&recs[sit].g[tid], (uint64_t)half | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (!have_prev) lds_barrier();      // (first trip only: see k_encode_reg_f32 -- lanes 0..3 have read red[] before any wave writes it again)
 
         if (have_prev) {
             // ---- 3. item i-1: the descriptor of its block (wave 0), then re-base and pack (lanes 0..127)

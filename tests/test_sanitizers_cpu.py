@@ -70,3 +70,23 @@ def test_text_reader_host_under_asan_ubsan(tmp_path):
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert "ok: 4 text host tests" in out and "runtime error:" not in out and "AddressSanitizer" not in out
+
+
+def test_minh_writer_teardown_under_asan_ubsan(tmp_path):
+    """tests/cpp/test_minh_writer_teardown.cpp: a minh::Writer (and its file-writer thread) destroyed with a task running and one
+    queued, and a Writer dropped without Close(); instrumented (use-after-free of f_ / cols_)"""
+    from minnow_amd import build as b
+    b.build()
+    lib_dir = os.path.join(ROOT, "minnow_amd")
+    exe = str(tmp_path / "test_minh_writer_teardown_san")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread"] + SAN + ["-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_minh_writer_teardown.cpp"), "-o", exe,
+                           "-L", lib_dir, "-lminnow_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    env = _env()
+    env.pop("LD_PRELOAD")
+    work = tmp_path / "w"
+    work.mkdir()
+    r = subprocess.run([exe, str(work)], capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "ok: minh writer teardown" in out and "runtime error:" not in out and "AddressSanitizer" not in out

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cstring>
 #define GLOBAL __attribute__((address_space(1)))
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -49,24 +50,38 @@ template <typename F> float best_of(F f, int reps) {
     return best;
 }
 
+static bool g_quiet = false;
+static double g_last_total = 0;
 template <int R, int W, bool NT> void run(const unsigned* src, unsigned* dst, long bytes_moved, const char* name) {
     // threads so that (R + W) * 16 B * threads = bytes_moved
     const long nthreads = bytes_moved / (16L * (R + W)) / 256 * 256;
     const long grid = nthreads / 256;
     const float ms = best_of([&] { hipLaunchKernelGGL((k_rw<R, W, NT>), dim3((unsigned)grid), dim3(256), 0, 0, src, dst, nthreads); }, 8);
     const double rd = 16.0 * R * nthreads, wr = 16.0 * W * nthreads;
-    printf("  %-34s %7.1f us   read %5.2f GB at %5.2f TB/s   written %5.2f GB at %5.2f TB/s   total %5.2f TB/s\n", name, ms * 1e3, rd / 1e9, rd / ms / 1e9, wr / 1e9,
+    g_last_total = (rd + wr) / ms / 1e6;      // GB/s
+    if (!g_quiet) printf("  %-34s %7.1f us   read %5.2f GB at %5.2f TB/s   written %5.2f GB at %5.2f TB/s   total %5.2f TB/s\n", name, ms * 1e3, rd / 1e9, rd / ms / 1e9, wr / 1e9,
            wr / ms / 1e9, (rd + wr) / ms / 1e9);
 }
 
 int main(int argc, char** argv) {
     const double gb = argc > 1 ? atof(argv[1]) : 6.0;
+    const bool json = argc > 2 && !strcmp(argv[2], "json");
+    g_quiet = json;
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
-    printf("device %s, pci bus %d; every kernel moves %.1f GB in all, 16 B per access, best of 8\n", prop.gcnArchName, prop.pciBusID, gb);
+    if (!json) printf("device %s, pci bus %d; every kernel moves %.1f GB in all, 16 B per access, best of 8\n", prop.gcnArchName, prop.pciBusID, gb);
     const long bytes = (long)(gb * 1e9);
     unsigned *src, *dst;
     CHK(hipMalloc(&src, bytes + 4096)); CHK(hipMalloc(&dst, bytes + 4096));
     CHK(hipMemset(src, 1, bytes)); CHK(hipMemset(dst, 2, bytes));
+    if (json) {
+        // the float codec's mixes at b = 18 only: 4 B read + 2.25 B written per element (encode), the reverse (decode)
+        run<9, 5, false>(src, dst, bytes, ""); const double e = g_last_total;
+        run<5, 9, false>(src, dst, bytes, ""); const double d = g_last_total;
+        run<1, 1, false>(src, dst, bytes, ""); const double c = g_last_total;
+        printf("{\"encode_mix_GBps\": %.1f, \"decode_mix_GBps\": %.1f, \"copy_GBps\": %.1f, \"pci_bus_id\": %d, \"what\": \"tools/microbench/rw_mix: %g GB moved per kernel, "
+               "one 16-byte access per thread in the codec's read : write ratio at 18 bits (9 : 5 and 5 : 9), no arithmetic, best of 8\"}\n", e, d, c, prop.pciBusID, gb);
+        return 0;
+    }
     run<1, 0, false>(src, dst, bytes, "read only");
     run<4, 0, false>(src, dst, bytes, "read only, 4 per thread");
     run<0, 1, false>(src, dst, bytes, "write only");
