@@ -586,9 +586,9 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
     // the quantization constants of the three components (the same for every sub-cell: mnw_vectors_encode fills them so)
     float qlow[3], qdx[3];
     double qrdx[3];
-    uint32_t qh[3];
+    uint32_t qh[3], qpx[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * s3]; qlow[k] = jb.low; qdx[k] = jb.dxq; qrdx[k] = jb.rdx; qh[k] = (uint32_t)(jb.pixels / 2); }
+    for (int k = 0; k < 3; ++k) { const DevJob& jb = jobs[k * s3]; qlow[k] = jb.low; qdx[k] = jb.dxq; qrdx[k] = jb.rdx; qh[k] = (uint32_t)(jb.pixels / 2); qpx[k] = (uint32_t)jb.pixels; }
     // everything the launch exchanges behind one buffer descriptor: item records, then the descriptor records
     const __amdgpu_buffer_rsrc_t rec_r = v3_rsrc(ra.recs, (n_item_recs * 2u + 3u * s3) * 16u);
     const uint32_t desc_off0 = n_item_recs * 32u;
@@ -889,12 +889,20 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
             if (!partial) quantize(std::true_type{}); else quantize(std::false_type{});
             uint32_t o3[3];
             wave_max12_u32(m12, o3);
-            // a wave whose least pixel index is <= 0 may hold a quotient in the denormal range, where the float64 multiply can
-            // round differently from the IEEE division: reload the floats and redo that component exactly (rare)
+            // Two rare cases send a wave back to its floats (reloaded; IEEE division):
+            //  * its least pixel index is <= 0: it may hold a quotient in the denormal range, where the float64 multiply can round
+            //    differently from the division;
+            //  * its largest pixel index is exactly `pixels`: a value that quantizes to the top of the ring (the data's maximum under
+            //    limits taken from the data, go/minp/minp.go:87-96: high = Nextafter32(max) can give (max - low) / dx == pixels).  The
+            //    reference's sequential periodicMin treats it as ring position 0 (periodicDistance wraps it), and bound() moves it
+            //    there whenever the arc's start is 0; recorded as 0 -- in the statistics and in the parked item -- it gives the
+            //    reference's (min, bits) and bytes in both cases: start a > 0 (narrow arc [a, pixels]: delta = 0 + pixels - a, the
+            //    wrapped-arc formulas) and start 0 (bound() makes it 0).  Anything beyond `pixels` stays out of the domain.
             {
-                // lane 1 holds the statistics 6..8 = (k = 1: umx, ~umn), (k = 2: max); the minima are values 1, 5, 9: lanes 0 (slot 1), 2 (slot 2 of 3..5 -> value 5), 3 (slot 0 of 9..11)
+                // wave_max12_u32: lane 0 holds the values 0..2, lane 1 the values 6..8, lane 2 the values 3..5, lane 3 the values 9..11
                 const int32_t mn0 = v3_dec_min((uint32_t)__shfl((int)o3[1], 0)), mn1 = v3_dec_min((uint32_t)__shfl((int)o3[2], 2)), mn2 = v3_dec_min((uint32_t)__shfl((int)o3[0], 3));
-                redo[0] = mn0 <= 0; redo[1] = mn1 <= 0; redo[2] = mn2 <= 0;
+                const int32_t mx0 = v3_dec_max((uint32_t)__shfl((int)o3[0], 0)), mx1 = v3_dec_max((uint32_t)__shfl((int)o3[1], 2)), mx2 = v3_dec_max((uint32_t)__shfl((int)o3[2], 1));
+                redo[0] = mn0 <= 0 || (uint32_t)mx0 == qpx[0]; redo[1] = mn1 <= 0 || (uint32_t)mx1 == qpx[1]; redo[2] = mn2 <= 0 || (uint32_t)mx2 == qpx[2];
             }
             if (__builtin_expect(redo[0] || redo[1] || redo[2], 0)) {
                 // (the floats are gone -- they became Q --: fetch them again; everything here is waited for before it is left)
@@ -913,7 +921,8 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                             for (int c = 0; c < 4; ++c) {
                                 const float x = *(const MNW_GLOBAL_SC float*)(gp + (off >> 2) + 3 * c + k);
                                 const float rq = __fdiv_rn(__fsub_rn(x, qlow[k]), qdx[k]);
-                                const int32_t q = cvt_floor_i32(rq);
+                                int32_t q = cvt_floor_i32(rq);
+                                if ((uint32_t)q == qpx[k]) q = 0;                         // the top of the ring is its position 0
                                 Q[k][4 * g + c] = (uint32_t)q;
                                 const uint32_t u = (uint32_t)q - qh[k];
                                 mn = min(mn, q); mx = max(mx, q); umn = min(umn, u); umx = max(umx, u);

@@ -1218,8 +1218,18 @@ def test_copy_file_to_device(mnw, ctx, torch_mod, tmp_path):
             ref[d:d + n] = data[o:o + n]
         assert np.array_equal(got, ref)
         # past the end of the file: an error, not a short copy
-        with pytest.raises(mnw.MnwError):
+        with pytest.raises(mnw.MnwError) as ei:
             ctx.copy_file_to_device(dev.data_ptr(), fd, [44_999_000], [5000])
+        assert ei.value.status == -8                      # MNW_E_IO: an I/O error, not a bad argument
+        # ... also in the middle of a transfer of several pinned chunks (earlier chunks are already on their way when the read
+        # fails): the call must have settled the ring, so the next one works and delivers the right bytes
+        with pytest.raises(mnw.MnwError):
+            ctx.copy_file_to_device(dev.data_ptr(), fd, [0, 44_000_000], [40_000_000, 2_000_000])
+        dev.zero_()
+        torch.cuda.synchronize()
+        ctx.copy_file_to_device(dev.data_ptr(), fd, offs, lens)
+        got = dev.cpu().numpy()
+        assert np.array_equal(got[: want.size], want)
     finally:
         os.close(fd)
 
