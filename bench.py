@@ -335,21 +335,27 @@ def leg_record(r, timing, note):
     }
 
 
-def minp_leg(mnw, ctx, device, reps, timing):
+def minp_leg(mnw, ctx, device, reps, timing, velocities=False):
     """configs[3], one rank's share: one minp file cell of 500^3 particles resident on the GPU, sub_cells = 5 -> 375
-    blocks of 1e6 per component (go/minp/minp.go:98-118): mnw_vectors_encode + mnw_vectors_decode."""
+    blocks of 1e6 per component (go/minp/minp.go:98-118): mnw_vectors_encode + mnw_vectors_decode.  Positions: the Lagrangian
+    grid + N(0, 2) wrapped into [0, 250), dx = 0.001, periodic; velocities: N(0, 300), dv = 1, limits from the data
+    (SURVEY.md 8d C4)."""
     from minnow_amd import minp
 
-    nf, S, L, dx = 500, 5, 250.0, 0.001
+    nf, S, L, dx = 500, 5, 250.0, (1.0 if velocities else 0.001)
+    periodic = not velocities
     n = nf ** 3
     g = torch.Generator(device=device)
-    g.manual_seed(0xACEDAD + 77)
-    idx = torch.arange(n, device=device)
-    pos = torch.stack([idx % nf, (idx // nf) % nf, idx // (nf * nf)], dim=1).to(torch.float32) * (L / nf)
-    del idx
-    pos.add_(torch.randn(pos.shape, device=device, generator=g).mul_(2.0))
-    pos = torch.remainder(pos, L).contiguous()
-    pos[pos >= L] = 0.0
+    g.manual_seed(0xACEDAD + (78 if velocities else 77))
+    if velocities:
+        pos = torch.randn((n, 3), device=device, generator=g, dtype=torch.float32).mul_(300.0).contiguous()
+    else:
+        idx = torch.arange(n, device=device)
+        pos = torch.stack([idx % nf, (idx // nf) % nf, idx // (nf * nf)], dim=1).to(torch.float32) * (L / nf)
+        del idx
+        pos.add_(torch.randn(pos.shape, device=device, generator=g).mul_(2.0))
+        pos = torch.remainder(pos, L).contiguous()
+        pos[pos >= L] = 0.0
     n_sub = nf // S
     nb = 3 * S ** 3
     slot = (4 * n_sub ** 3 + 15) // 16 * 16
@@ -359,11 +365,11 @@ def minp_leg(mnw, ctx, device, reps, timing):
     state = {}
 
     def enc():
-        state["m"] = minp.vectors_encode(ctx, pos.data_ptr(), nf, S, dx, True, L, packed.data_ptr(), slot)
+        state["m"] = minp.vectors_encode(ctx, pos.data_ptr(), nf, S, dx, periodic, L, packed.data_ptr(), slot)
 
     def dec():
         metas, low, high, pixels = state["m"]
-        minp.vectors_decode(ctx, packed.data_ptr(), slot, metas, nf, S, low, high, pixels, True, L, out.data_ptr(), seed=1)
+        minp.vectors_decode(ctx, packed.data_ptr(), slot, metas, nf, S, low, high, pixels, periodic, L, out.data_ptr(), seed=1)
 
     def both():
         enc()
@@ -389,12 +395,17 @@ def minp_leg(mnw, ctx, device, reps, timing):
     metas = state["m"][0]
     pb = float(sum(m.nbytes for m in metas))
     d = (out.double() - pos.double()).abs()
-    d = torch.minimum(d, L - d)
-    assert float(d.max()) <= dx * 1.01 + 1e-4
+    if periodic:
+        d = torch.minimum(d, L - d)
+        assert float(d.max()) <= dx * 1.01 + 1e-4
+    else:
+        # (the reference's quirk: a component's maximum can quantize to `pixels` and is read back at the bottom of the range)
+        assert int((d > dx * 1.01 + 1e-3).sum()) <= 3
     alg = 12.0 * n + pb
     enc_us = sum(v for k, v in kt.items() if k in ("k_encode_reg_vec3", "k_reduce_vec3", "k_pack_vec3", "k_subcell_gather", "k_encode_reg_f32", "k_reduce_f32", "k_pack_f32"))
     dec_us = sum(v for k, v in kt.items() if k in ("k_unpack_vec3", "k_unpack_f32", "k_subcell_scatter"))
-    rec = {"n_file": nf, "sub_cells": S, "particles": n, "blocks": nb, "bits": sorted(set(m.bits for m in metas)),
+    rec = {"what": "velocities N(0,300), dv = 1, data-derived limits" if velocities else "positions, dx = 0.001, periodic",
+           "n_file": nf, "sub_cells": S, "particles": n, "blocks": nb, "bits": sorted(set(m.bits for m in metas)),
            "ms_per_step": dt * 1e3, "value": 12.0 * n / dt / 1e9, "unit": "GB/s of input (12 B per particle), encode + decode",
            "kernel_us": kt, "algorithmic_bytes_per_pass": alg}
     if enc_us and dec_us:
@@ -609,6 +620,8 @@ def main():
                                                    "slowest_rank_ms_per_step": slowest * 1e3,
                                                    "value": 12.0 * world * extra["minp_cell"]["particles"] / slowest / 1e9,
                                                    "unit": "GB/s of input (12 B per particle), encode + decode, all ranks"}
+            torch.cuda.empty_cache()
+            extra["minp_cell_velocities"] = minp_leg(mnw, ctx, device, 5, timing, velocities=True)
             torch.cuda.empty_cache()
             extra["catalogue_c3"] = catalogue_leg(mnw, ctx, device, 10 ** 8, 3, timing)
     counters = ctx.counters()

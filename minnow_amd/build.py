@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminnow_hip.so")
 SOURCES = ["mnw_kernels.hip", "mnw_api.cpp"]
-HEADERS = ["mnw_common.h", "mnw_subcell.hip", "mnw_minh.hip", "mnw_text.hip", "mnw_text_num.h", "mnw_pow10_table.h", "mnw_cut.hip", "mnw_fast_tables.h", "mnw_gomath_fast.h", os.path.join("..", "..", "include", "minnow_hip.h")]
+HEADERS = ["mnw_common.h", "mnw_subcell.hip", "mnw_minh.hip", "mnw_text.hip", "mnw_text_num.h", "mnw_pow10_table.h", "mnw_cut.hip", "mnw_fast_tables.h", "mnw_gomath_fast.h", "mnw_diag.h", os.path.join("..", "..", "include", "minnow_hip.h")]
 
 # -ffp-contract=off: the reference's float32 expressions are never fused (Go on amd64);
 # correctly rounded f32 divide and denormal support are hipcc defaults, stated explicitly here.

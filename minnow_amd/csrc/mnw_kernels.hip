@@ -667,26 +667,7 @@ __device__ __forceinline__ float quant_mul(float x, float low, double rdx) {
 // pack pass, float32 blocks (32-bit path: q in [0,pixels), pixels < 2^31, or int32-range q when
 // not periodic)
 // ------------------------------------------------------------------------------------------------
-// Diagnostic builds only (-DMNW_STAMPS, tools/microbench): per-phase cycle sums of wave 0 of every
-// workgroup, written to a buffer no other code reads.  The shipped library has no stamps.
-#ifdef MNW_STAMPS
-__device__ unsigned long long* g_stamp_abs = nullptr;
-__device__ unsigned long long* g_stamp_buf = nullptr;
-__device__ int g_dbg_skip = 0;
-#define MNW_STAMP_DECL unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_c0 = __builtin_amdgcn_s_memtime();
-#define MNW_STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#ifdef MNW_STAMPS_LIGHT     // start and end of every workgroup only: the kernel as shipped but for two clock reads
-#define MNW_STAMP(i)
-#else
-#define MNW_STAMP(i) { unsigned long long t2_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc[i] += t2_ - st_t; st_t = t2_; }
-#endif
-#define MNW_STAMP_FLUSH if (g_stamp_buf && threadIdx.x == 0) { const unsigned long long e_ = __builtin_amdgcn_s_memrealtime(); st_acc[7] = e_ - st_rt0; st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0; for (int i_ = 0; i_ < 8; ++i_) g_stamp_buf[blockIdx.x * 8 + i_] += st_acc[i_]; if (g_stamp_abs) { g_stamp_abs[blockIdx.x * 2] = st_rt0; g_stamp_abs[blockIdx.x * 2 + 1] = e_; } }
-#else
-#define MNW_STAMP_DECL
-#define MNW_STAMP_START
-#define MNW_STAMP(i)
-#define MNW_STAMP_FLUSH
-#endif
+#include "mnw_diag.h"     // cycle stamps and counters of the diagnostic builds (tools/microbench); expands to nothing in the library
 
 // Descriptor of job j for the pack phase.  After a kernel boundary it is simply there; inside the
 // fused launch one lane polls the 8-byte word (relaxed agent-scope load, bounded spin: a timeout or
@@ -893,11 +874,6 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
     __shared__ uint64_t shared_slot;
     __shared__ Pending pend;
     const int slot = blockIdx.x % kStatSlots;
-#ifdef MNW_STAMPS
-    const int dbg_skip = g_dbg_skip;     // diagnostic builds only: 1 = no reduce phase, 2 = no pack phase
-#else
-    constexpr int dbg_skip = 0;
-#endif
     if (threadIdx.x == 0) pend.cnt = 0;
     __syncthreads();
     for (int g = 0; g <= ngroups; ++g) {
@@ -914,13 +890,13 @@ __global__ __launch_bounds__(kThreads) void k_encode_f32(const DevJob* __restric
                 pref = __hip_atomic_load(&sync[jl].granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        const bool packs = g >= 1 && pa < pb && !(dbg_skip & 2);
-        if (g < ngroups && !(dbg_skip & 1)) {
+        const bool packs = g >= 1 && pa < pb;
+        if (g < ngroups) {
             const int64_t a = gtile[g], n = gtile[g + 1] - a;
             reduce_range_f32(jobs, gjob[g], gjob[g + 1], a + n * blockIdx.x / gridDim.x,
                              a + n * (blockIdx.x + 1) / gridDim.x, stats, sync, meta, slot, red, redbad, &pend, packs);
         }
-        if (g >= 1 && !(dbg_skip & 2)) {
+        if (g >= 1) {
             if (!pack_range_f32<true>(lds, &shared_slot, jobs, gjob[g - 1], gjob[g], pa, pb, sync, abort_flag, pref,
                                       &pend, stats, meta)) return;
         }
@@ -1139,12 +1115,6 @@ __device__ __forceinline__ bool poll_abort(uint32_t& spins, uint64_t t_start, ui
     return false;
 }
 
-#ifdef MNW_STAMPS
-__device__ unsigned long long g_big_diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // calls, group polls, block polls, cycles: all / group phase / block phase
-#define MNW_BIG_DIAG(i, v) if (lane_id() == 0) atomicAdd(&g_big_diag[i], (unsigned long long)(v))
-#else
-#define MNW_BIG_DIAG(i, v)
-#endif
 // wave 0 only.  Large blocks, the two steps of the two-level sweep:
 //   group_duty_f32: poll the item records of the group of item `it` of job j until all are there, fold them and publish
 //      the group record.  Every member of a group does this (no leader; it waits for item records only), in the trip in
@@ -1256,9 +1226,6 @@ __constant__ int kRoundTable[kRoundTables][kMaxRounds] = {
 };
 // (measured against 14/13/12/11, 14/14/12/11 and 14/11/10/9: within 1 % at 1e8 elements, best at 1e9)
 
-#ifdef MNW_STAMPS
-__device__ unsigned long long g_slow_sweeps = 0;
-#endif
 
 // XF: the batch has jobs with a minh value transform (DevJob.xform).  A separate instantiation: the plain kernel has
 // no scalar or vector register to spare, and carrying the transform's code and state cost it 6 %.  (The XF one
@@ -1290,12 +1257,6 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
     const int tid = threadIdx.x;
     MNW_STAMP_DECL
     MNW_STAMP_START
-#ifdef MNW_DIAG_SETPRIO       // diagnostic builds only: issue priority against the hardware's preference for a CU's oldest waves
-    { const int q = (int)(blockIdx.x * 4u / gridDim.x);
-      if (MNW_DIAG_SETPRIO == 1) { if (q == 1) __builtin_amdgcn_s_setprio(1); else if (q == 2) __builtin_amdgcn_s_setprio(2); else if (q == 3) __builtin_amdgcn_s_setprio(3); }
-      if (MNW_DIAG_SETPRIO == 2) { if (q == 3) __builtin_amdgcn_s_setprio(1); }
-      if (MNW_DIAG_SETPRIO == 3) { if (q >= 2) __builtin_amdgcn_s_setprio(1); } }
-#endif
 
     // the item in e[] (all wave-uniform)
     u32x4 e[kV];
@@ -1521,9 +1482,6 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                     fl |= swf[w];
                 }
                 uint64_t g;
-#ifdef MNW_DIAG_NOWAIT
-                fl &= ~1u;                           // diagnostic build: never wait for a record (output is then wrong)
-#endif
                 if (BIG && pitems > kMaxSweep) {
                     // a large block.  Its descriptor may be known from the trip before (the workgroup's previous item was in
                     // the same block); else: the current item's group first if that is part of the block, then the sweep
@@ -1543,9 +1501,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* _
                         desc_job = pj; desc_word = g;
                     }
                 } else if (__builtin_expect(fl & 1u, 0)) {
-#ifdef MNW_STAMPS
-                    if (lane_id() == 0) atomicAdd(&g_slow_sweeps, 1ull);
-#endif
+                    MNW_DIAG_SLOW_SWEEP
                     g = sweep_block_f32(jobs, pj, recs, gen, abort_flag, abort_host, meta, pit == pjb.tile0);
                 } else {
                     g = desc_from_sweep_f32(pjb, pj, v0, v1, v2, v3, (fl & 2u) != 0, meta, pit == pjb.tile0);
@@ -2213,12 +2169,8 @@ __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restric
                         }
                         qd = (double)q;
                     }
-#ifdef MNW_DIAG_NO_DITHER      // diagnostic builds only (tools/microbench): price the dither
-                    const double u = 0.0; (void)ka; (void)kb;
-#else
                     const uint32_t z = dither_bits((uint32_t)(base + i), ka, kb);
                     const double u = (double)z * (1.0 / 4294967296.0);
-#endif
                     // group.go:308: dx*float32(float64(q) + u) + low, float32 multiply then add
                     r[c] = __fadd_rn(__fmul_rn(dx, (float)__dadd_rn(qd, u)), low);
                 }

@@ -463,16 +463,6 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
 // order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the call through
 // k_reduce_vec3 + k_pack_vec3.   HBM traffic = algorithmic: 12 B/particle read + the streams (+ 96 B of records per item).
 // ------------------------------------------------------------------------------------------------
-#if defined(MNW_STAMPS)     // diagnostic builds only (tools/microbench/vec3_stamps.hip): how often a descriptor is late, per workgroup (wave 0)
-__device__ unsigned long long* g_v3_diag = nullptr;
-#define MNW_V3_COUNT_DECL unsigned long long v3c_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define MNW_V3_COUNT(i) { v3c_[i] += 1; }
-#define MNW_V3_COUNT_FLUSH if (g_v3_diag && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_v3_diag[blockIdx.x * 8 + i_] += v3c_[i_]; }
-#else
-#define MNW_V3_COUNT_DECL
-#define MNW_V3_COUNT(i)
-#define MNW_V3_COUNT_FLUSH
-#endif
 struct Vec3RegArgs {
     Vec3Args a;
     ItemRec* recs;            // [3 s3][T] item records, then [3 s3] 16-byte descriptor records
@@ -1040,12 +1030,8 @@ __device__ __forceinline__ sc_f32x4 v3_dequant4(const V3Dec& d, const uint32_t* 
         // group.go:262, then bound(buf, 0, pixels) with q >= 0: one wrap from above, as an unsigned minimum
         uint32_t q = d.mn + v3_extract(l32, pos0 + (uint32_t)c * d.b, d.mask);
         q = min(q, q - d.wrap);
-#ifdef MNW_DIAG_NO_DITHER       // diagnostic builds only: price the dither and the float64 detour
-        const float f = (float)(int32_t)q;
-#else
         const uint32_t z = dither_bits(j + (uint32_t)c, d.ka, d.kb);
         const float f = (float)__fma_rn((double)z, 0x1p-32, (double)(int32_t)q); // float32(float64(q) + u), u = z 2^-32 exactly
-#endif
         o[c] = __fadd_rn(__fmul_rn(d.dx, f), d.low);                             // group.go:308: float32 multiply, then add
     }
     // minp.go:188-196, only for blocks in which it can fire (selects, not branches: the conditions differ from lane to lane)
@@ -1182,11 +1168,7 @@ __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restri
                     const uint32_t g = __umulhi(c, 0x55555556u), part = c - 3 * g;      // c / 3 for c < 2^31
                     const u32x4 ch = *reinterpret_cast<const u32x4*>(img + 4 * c);
                     const uint32_t off = img[64 * 12 + g];
-#ifdef MNW_DIAG_V3_NOSTORE      // diagnostic builds only: price the grid stores
-                    __builtin_amdgcn_raw_buffer_store_b128(ch, grid_r, (int)(ch.x == 0x7fc00001u ? off + 16 * part : kV3NoStore), 0, 0);
-#else
                     __builtin_amdgcn_raw_buffer_store_b128(ch, grid_r, (int)(off + 16 * part), 0, 0);       // (kV3NoStore + 16 part: out of range)
-#endif
                 }
                 // (the next pass overwrites the image: its writes follow these reads in the wave's LDS queue)
             }

@@ -25,7 +25,6 @@ int main(int argc, char** argv) {
     CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &sb, sizeof(sb)));
     unsigned long long* sabs; CHK(hipMalloc(&sabs, 16 * 4096)); CHK(hipMemset(sabs, 0, 16 * 4096));
     CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_abs), &sabs, sizeof(sabs)));
-    CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_skip), &skip, sizeof(skip)));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, x, n); CHK(hipDeviceSynchronize());
     int nj = (int)((n + B - 1) / B);
     std::vector<DevJob> hj(nj); long items = 0;

@@ -202,14 +202,20 @@ int main(int argc, char** argv) {
                 std::snprintf(buf, sizeof buf, "%s\"%s\": %.4f", kjson.empty() ? "" : ", ", mnw_kernel_name(k), kt[k].total_ms);
                 kjson += buf;
             }
+        // how often the single-read encode kernels gave up and how many batches skipped them afterwards: not 0 means something else
+        // was running on the GPU and the conversion paid 50 ms waits and the two-launch reruns (minnow_hip.h: mnw_counters_get)
+        int64_t cnt[MNW_C_COUNT] = {0};
+        mnw_counters_get(ctx, cnt);
         std::FILE* fo = std::fopen(out.c_str(), "rb");
         std::fseek(fo, 0, SEEK_END);
         const long outBytes = std::ftell(fo);
         std::fclose(fo);
         std::printf("{\"text_bytes\": %lld, \"blocks\": %d, \"rows\": %lld, \"rows_kept\": %lld, \"minh_bytes\": %ld, \"total_s\": %.6f, "
-                    "\"block_s\": %.6f, \"upload_wait_s\": %.6f, \"upload_thread_s\": %.6f, \"cut_s\": %.6f, \"minh_block_s\": %.6f, \"text_GBps\": %.4f, \"kernel_ms\": {%s}, \"kernels_total_ms\": %.4f}\n",
+                    "\"block_s\": %.6f, \"upload_wait_s\": %.6f, \"upload_thread_s\": %.6f, \"cut_s\": %.6f, \"minh_block_s\": %.6f, \"text_GBps\": %.4f, \"kernel_ms\": {%s}, \"kernels_total_ms\": %.4f, "
+                    "\"single_read_aborts\": %lld, \"backoff_batches\": %lld, \"exact_blocks\": %lld}\n",
                     (long long)bytesIn, fR->Blocks(), (long long)rowsIn, (long long)rowsKept, outBytes, total, tParse, fR->UploadWaitSeconds(), fR->UploadSeconds(), tCut, tWrite,
-                    (double)bytesIn / total / 1e9, kjson.c_str(), kms);
+                    (double)bytesIn / total / 1e9, kjson.c_str(), kms, (long long)cnt[MNW_C_SINGLE_READ_ABORTS], (long long)cnt[MNW_C_BACKOFF_BATCHES],
+                    (long long)cnt[MNW_C_EXACT_BLOCKS]);
         return 0;
     } catch (const std::exception& e) {
         std::cerr << "panic: " << e.what() << "\n";
