@@ -55,8 +55,8 @@ int64_t vec3_reg_recs(int64_t, int64_t);
 int64_t vec3_reg_max_tiles_per_block();
 int vec3_reg_sweepers();
 bool vec3_reg_geometry_ok(int64_t, int64_t);
-int encode_reg_vec3_blocks_per_cu(bool);
-void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t, int, bool);
+int encode_reg_vec3_blocks_per_cu(int);
+void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t, int, int);
 void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float, int, bool, int);
 bool vec3_unpack_geometry_ok(int64_t, int64_t);
 constexpr int kMinhBatch = 64;
@@ -290,8 +290,8 @@ struct mnw_ctx {
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
     int vec3_x_order = 1;        // minp vector kernels: workgroups in dispatch order take the sub-cells of one x-row together
     int vec3_unpack_db = 1;      // k_unpack_vec3: two LDS word buffers and one barrier per vtile (0: one buffer, two barriers, more workgroups per CU)
-    int vec3_deep = 1;           // k_encode_reg_vec3: four items per workgroup (three workgroups per CU) rather than three (four per CU)
-    int vec3_round_table = 0;    // k_encode_reg_vec3: 0 = every round a whole grid, k > 0 = the weighted hand-out of k_encode_reg_f32 with its table k - 1
+    int vec3_deep = 4;           // k_encode_reg_vec3: items per workgroup between a vtile's publication and its pack (3: four workgroups per CU; 4, 5: three)
+    int vec3_round_table = 4;    // k_encode_reg_vec3 (depth 4, 5): 0 = every round a whole grid, k > 0 = weighted hand-out by thirds of the grid, table k - 1 (4: 10 / 9 / 8 items per cycle)
     int vec3_single_read = 1;    // minp vectors: the grid is read once (k_encode_reg_vec3) when the geometry allows and its grid can be co-resident;
                                  // 0: k_reduce_vec3 + k_pack_vec3, which read it twice (also what reruns the call when the single-read launch gives up)
     int reg_i64_blocks_per_cu = 0; // co-resident workgroups of k_encode_reg_i64 per CU
@@ -1223,7 +1223,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "host_threads")) { if (c->stg.ready) return fail(c, MNW_E_ARG, "host_threads must be set before the first host-pointer call"); c->host_threads = (int)value; return MNW_OK; }
     if (!strcmp(name, "stage_min_bytes")) { c->stage_min = value; return MNW_OK; }
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
-    if (!strcmp(name, "vec3_deep")) { c->vec3_deep = value != 0; c->reg_vec3_blocks_per_cu = 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_deep")) { c->vec3_deep = value < 3 ? 3 : value > 5 ? 5 : (int)value; c->reg_vec3_blocks_per_cu = 0; return MNW_OK; }
     if (!strcmp(name, "vec3_round_table")) { c->vec3_round_table = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_x_order")) { c->vec3_x_order = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_db")) { c->vec3_unpack_db = value != 0; return MNW_OK; }
@@ -1672,7 +1672,7 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
         }
         if (c->vec3_single_read && !v3_backing_off) {
             if (c->reg_vec3_blocks_per_cu == 0) {
-                const int occ = mnw::encode_reg_vec3_blocks_per_cu(c->vec3_deep != 0);
+                const int occ = mnw::encode_reg_vec3_blocks_per_cu(c->vec3_deep);
                 c->reg_vec3_blocks_per_cu = occ < 1 ? -1 : (occ > 3 ? 3 : occ);
             }
             int64_t grid = (int64_t)c->cus * c->reg_vec3_blocks_per_cu;
@@ -1680,6 +1680,7 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
             // (the last vec3_reg_sweepers() workgroups of the grid hold no items: they derive the sub-cells' descriptors)
             const int64_t nsw = mnw::vec3_reg_sweepers();
             if (vt + nsw < grid) grid = vt + nsw;
+            else grid -= (grid - nsw) % 3;               // (the item workgroups in three equal thirds: the weighted hand-out)
             const int64_t T = vt / s3;
             if (c->reg_vec3_blocks_per_cu >= 1 && T <= grid - nsw && T <= mnw::vec3_reg_max_tiles_per_block() && mnw::vec3_reg_geometry_ok(n_file, sub_cells)) {
                 const size_t need = (size_t)mnw::vec3_reg_recs(n_file, sub_cells) * mnw::item_rec_bytes();
@@ -1696,7 +1697,7 @@ int mnw_vectors_encode(mnw_ctx* c, mnw_stream_t stream, const float* vec, int64_
                 sl->h_sync[0] = 0;
                 { ScopedTimer t(c, s, MNW_K_ENCODE_REG_VEC3);
                   mnw::launch_encode_reg_vec3(s, (int)grid, vec, n_file, sub_cells, sl->d_jobs, c->d_recs, c->reg_gen, abort_ptr(sl), sl->d_hsync,
-                                              sl->d_meta, c->reg_drop_item, c->vec3_round_table, c->vec3_deep != 0); }
+                                              sl->d_meta, c->reg_drop_item, c->vec3_round_table, c->vec3_deep); }
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, wait_stream(s));
                 c->counters[MNW_C_VEC3_SINGLE_READ_CALLS]++;

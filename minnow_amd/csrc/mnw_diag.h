@@ -27,7 +27,12 @@ __device__ unsigned long long* g_v3_diag = nullptr;
 #define MNW_V3_COUNT_DECL unsigned long long v3c_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MNW_V3_COUNT(i) { v3c_[i] += 1; }
 #define MNW_V3_COUNT_FLUSH if (g_v3_diag && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_v3_diag[blockIdx.x * 8 + i_] += v3c_[i_]; }
+// k_encode_reg_vec3 time line (100 MHz clock): [0 .. items): when an item's records were published; [items .. 2 items): when its
+// descriptor was first looked for; [2 items .. 3 items): when it was there; then per sub-cell: sentinel seen, descriptors published
+__device__ unsigned long long* g_v3_trace = nullptr;
+#define MNW_V3_TRACE(idx) if (g_v3_trace && (threadIdx.x & 63) == 0) g_v3_trace[idx] = __builtin_amdgcn_s_memrealtime();
 #else
+#define MNW_V3_TRACE(idx)
 #define MNW_STAMP_DECL
 #define MNW_STAMP_START
 #define MNW_STAMP(i)

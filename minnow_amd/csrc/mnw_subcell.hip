@@ -463,6 +463,18 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
 // order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the call through
 // k_reduce_vec3 + k_pack_vec3.   HBM traffic = algorithmic: 12 B/particle read + the streams (+ 96 B of records per item).
 // ------------------------------------------------------------------------------------------------
+// Round sizes of k_encode_reg_vec3's weighted hand-out, in THIRDS of the grid (three workgroups per CU: a CU's three come from the
+// three thirds of the grid in dispatch order, and the hardware favours the oldest -- measured: the first eighth of the workgroups
+// found its descriptors late 65 % of the time, the last 19 %, i.e. the late ones set the pace).  Table k gives the thirds
+// 8:7:6, 7:6:5, 9:8:7, 10:9:8 items per cycle; no two partial rounds adjacent (k_encode_reg_f32's rule).
+constexpr int kV3Tables = 4;
+__constant__ int kV3RoundCount[kV3Tables] = {8, 7, 9, 10};
+__constant__ int kV3RoundTable[kV3Tables][10] = {
+    {3, 3, 1, 3, 3, 3, 2, 3},
+    {3, 3, 1, 3, 3, 2, 3},
+    {3, 3, 3, 1, 3, 3, 3, 2, 3},
+    {3, 3, 3, 1, 3, 3, 3, 2, 3, 3},
+};
 struct Vec3RegArgs {
     Vec3Args a;
     ItemRec* recs;            // [3 s3][T] item records, then [3 s3] 16-byte descriptor records
@@ -549,11 +561,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t v3_rsrc(const void* base, uint
     return __builtin_amdgcn_make_buffer_rsrc((void*)pu, 0, (int)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
-// DEEP: one more item in registers (P, quantized two trips ago) between Q and the planes: a descriptor is then asked for two whole
-// trips after its sub-cell's last record instead of one, at 168 registers and three workgroups per CU instead of 128 and four
-template <bool DEEP>
-__global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegArgs ra, const DevJob* __restrict__ jobs, Meta* __restrict__ meta) {
+// DEPTH: items between a vtile's publication and its pack.  3: F, Q, planes (128 registers, four workgroups per CU).  4: one more
+// item in registers (P, quantized two trips ago).  5: another one waiting in lane-private LDS slots (W) -- at three workgroups per
+// CU, which the registers of 4 already cost, half the LDS is idle.  A descriptor is needed DEPTH - 2 whole trips after its
+// sub-cell's last record; it arrives two memory hops and a sweep after that (10-17 us measured, against trips of 5.5-7.5 us).
+template <int DEPTH>
+__global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec3RegArgs ra, const DevJob* __restrict__ jobs, Meta* __restrict__ meta) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[3 * kVPlane];
+    __shared__ __attribute__((aligned(16))) uint32_t wait_s[DEPTH == 5 ? 6 : 1][256][4];   // DEPTH 5: the item W, lane-private
     __shared__ uint32_t red[12][4];                      // the item's statistics per wave, max form
     __shared__ int redbad[4];
     __shared__ Vec3JobPar jpar[3];
@@ -603,6 +618,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                 if (((w.y | kRecBad) ^ (gen | kRecBad)) == 0) break;
                 if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; break; }
             }
+            if (wv == 0) { MNW_V3_TRACE(3 * total + 2 * sc_) }
             lds_barrier();
             if (abort_s) return;
             for (;;) {
@@ -663,6 +679,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                         const u32x4 rec = {(uint32_t)(int32_t)d.imin, gen, info, gen};
                         __builtin_amdgcn_raw_buffer_store_b128(rec, rec_r, (int)(desc_off0 + (uint32_t)j * 16u), 0, 16);
                     }
+                    if (wv == 3) { MNW_V3_TRACE(3 * total + 2 * sc_ + 1) }
                     lds_barrier();                               // (red / redbad are free again)
                     break;
                 }
@@ -716,21 +733,21 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
     // round sizes cycle through a table in quarters of the grid (no two partial rounds adjacent: two consecutive items of a
     // workgroup stay at least a whole grid, hence at least T items, apart)
     const int weighted = ra.weighted;
-    const uint32_t unit = weighted ? G / 4 : G;
+    const uint32_t unit = weighted ? G / 3 : G;
     int round = 0;
     uint32_t round_base = 0;
     auto next_item = [&]() -> uint32_t {
         for (;;) {
-            round_base += (uint32_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit;
-            round = round + 1 == (weighted ? kRoundCount[weighted - 1] : 1) ? 0 : round + 1;
+            round_base += (uint32_t)(weighted ? kV3RoundTable[weighted - 1][round] : 1) * unit;
+            round = round + 1 == (weighted ? kV3RoundCount[weighted - 1] : 1) ? 0 : round + 1;
             if (round_base >= total) return total;
-            if (blockIdx.x < (uint32_t)(weighted ? kRoundTable[weighted - 1][round] : 1) * unit) return round_base + blockIdx.x;
+            if (blockIdx.x < (uint32_t)(weighted ? kV3RoundTable[weighted - 1][round] : 1) * unit) return round_base + blockIdx.x;
         }
     };
     uint32_t nit = blockIdx.x;                          // round 0 is a full one
-    uint32_t nsc = T == 1 ? nit : __umulhi(nit, ra.m_T), nt = nit - nsc * T, qsc = 0, qt = 0, psc = 0, pt = 0, osc = 0, ot = 0;
-    bool have_n = nit < total, have_q = false, have_p = false, have_o = false;
-    uint32_t P[3][8];                                    // DEEP: the item quantized two trips ago
+    uint32_t nsc = T == 1 ? nit : __umulhi(nit, ra.m_T), nt = nit - nsc * T, qsc = 0, qt = 0, psc = 0, pt = 0, wsc = 0, wt = 0, osc = 0, ot = 0;
+    bool have_n = nit < total, have_q = false, have_p = false, have_w = false, have_o = false;
+    uint32_t P[3][8];                                    // DEPTH >= 4: the item quantized two trips ago
     uint32_t Q[3][8];                                    // pixel indices of the Q item: component k, the lane's 8 particles
     issue_desc(false, 0);
     issue_floats(have_n, nsc, nt);
@@ -739,7 +756,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
     MNW_STAMP_START
     lds_barrier();
 
-    while (have_n || have_q || have_p || have_o) {
+    while (have_n || have_q || have_p || have_w || have_o) {
         // ---- 1. pack the parked item (waves 0..2) | sweep duty (wave 3) ---------------------------------------------------------
         {
             // (all waves run the same vector-memory instructions: eight chunk stores and one tail store; wave 3's are out of range)
@@ -754,6 +771,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                 // the descriptor, requested a trip ago; poll if the sub-cell's owner has not got there yet
                 const Vec3JobPar& jp = jpar[wv];
                 uint32_t imin = dsc_rec.x, info = dsc_rec.z;
+                if (wv == 0) { MNW_V3_TRACE(total + osc * T + ot) }
                 MNW_V3_COUNT(0);
                 if (__builtin_expect(((dsc_rec.y ^ gen) | (dsc_rec.w ^ gen)) != 0, 0)) {
                     uint32_t spins = 0;
@@ -761,6 +779,9 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                     MNW_V3_COUNT(1);
                     for (;;) {
                         MNW_V3_COUNT(2);
+                        // (a workgroup that waits here is AHEAD of the ones whose records the descriptor is waiting for, some of them
+                        // on this CU: it must not take issue slots and memory requests from them -- sleep between looks)
+                        __builtin_amdgcn_s_sleep(64);
                         const u32x4 d2 = __builtin_amdgcn_raw_buffer_load_b128(rec_r, (int)(desc_off0 + ((uint32_t)wv * s3 + osc) * 16u), 0, 16);
                         if (((d2.y ^ gen) | (d2.w ^ gen)) == 0) { imin = d2.x; info = d2.z; break; }
                         if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; info = 0x100u; break; }
@@ -768,6 +789,7 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                 }
                 // info: bits 0..6 width, bit 7 pmin == imin, bits 8.. status code (0 ok)
                 imin = (uint32_t)__builtin_amdgcn_readfirstlane((int)imin); info = (uint32_t)__builtin_amdgcn_readfirstlane((int)info);
+                if (wv == 0) { MNW_V3_TRACE(2 * total + osc * T + ot) }
                 MNW_STAMP(0)      // the descriptor is there (wait for its load, or poll)
                 bw = (info >> 8) == 0 ? (info & 0x7fu) : 0u;
                 if (bw != 0) {
@@ -816,20 +838,28 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
         lds_barrier();                                   // every lane holds what it needed of the planes
         MNW_STAMP(2)          // barrier
         if (abort_s) break;
-        // ---- 2. Q (DEEP: P, then Q becomes P) -> the planes ----------------------------------------------------------------------------
-        if (DEEP ? have_p : have_q) {
+        // ---- 2. the oldest waiting item -> the planes; the others move up (Q -> P -> W) -----------------------------------------------
+        {
+            const int ot_ = opaque_tid();
+            const bool have_x = DEPTH == 5 ? have_w : DEPTH == 4 ? have_p : have_q;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const uint32_t e = 4 * (uint32_t)(opaque_tid() + 256 * g);                // element of the vtile
+                const uint32_t e = 4 * (uint32_t)(ot_ + 256 * g);                          // element of the vtile
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const u32x4 v = DEEP ? u32x4{P[k][4 * g], P[k][4 * g + 1], P[k][4 * g + 2], P[k][4 * g + 3]}
-                                         : u32x4{Q[k][4 * g], Q[k][4 * g + 1], Q[k][4 * g + 2], Q[k][4 * g + 3]};
-                    *reinterpret_cast<u32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = v;
+                    u32x4 v;
+                    if (DEPTH == 5) {
+                        u32x4* slot = reinterpret_cast<u32x4*>(&wait_s[3 * g + k][ot_][0]);
+                        v = *slot;
+                        const u32x4 pv = {P[k][4 * g], P[k][4 * g + 1], P[k][4 * g + 2], P[k][4 * g + 3]};
+                        *slot = pv;
+                    } else if (DEPTH == 4) v = u32x4{P[k][4 * g], P[k][4 * g + 1], P[k][4 * g + 2], P[k][4 * g + 3]};
+                    else v = u32x4{Q[k][4 * g], Q[k][4 * g + 1], Q[k][4 * g + 2], Q[k][4 * g + 3]};
+                    if (have_x) *reinterpret_cast<u32x4*>(lds + k * kVPlane + stage32_idx((int)e)) = v;
                 }
             }
         }
-        if (DEEP) {
+        if (DEPTH >= 4) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -946,14 +976,16 @@ __global__ __launch_bounds__(256, DEEP ? 3 : 4) void k_encode_reg_vec3(Vec3RegAr
                 off = (((uint32_t)k * s3 + nsc) * T + nt) * 32u + 8u * (uint32_t)w4;
             }
             __builtin_amdgcn_raw_buffer_store_b64(w64, rec_r, (int)off, 0, 16);           // sc1
+            if (wv == 3 && have_n) { MNW_V3_TRACE(nit) }
         }
         // ---- 6. requests of the next trip: the descriptor of the sub-cell now parked (a sweeper publishes it once the sub-cell's last
         // record is out; a request that comes back empty costs polled round trips at the start of the next trip, so it is made as
         // late as possible), then the next item's floats
-        issue_desc(DEEP ? have_p : have_q, DEEP ? psc : qsc);
+        issue_desc(DEPTH == 5 ? have_w : DEPTH == 4 ? have_p : have_q, DEPTH == 5 ? wsc : DEPTH == 4 ? psc : qsc);
         issue_floats(have_next, nsc2, nt2);
         MNW_STAMP(5)          // barrier, publish (and the sweep duty, once per sub-cell), requests
-        if (DEEP) { have_o = have_p; osc = psc; ot = pt; have_p = have_q; psc = qsc; pt = qt; }
+        if (DEPTH == 5) { have_o = have_w; osc = wsc; ot = wt; have_w = have_p; wsc = psc; wt = pt; have_p = have_q; psc = qsc; pt = qt; }
+        else if (DEPTH == 4) { have_o = have_p; osc = psc; ot = pt; have_p = have_q; psc = qsc; pt = qt; }
         else { have_o = have_q; osc = qsc; ot = qt; }
         have_q = have_n; qsc = nsc; qt = nt;
         nit = nit2; nsc = nsc2; nt = nt2;
@@ -1242,23 +1274,25 @@ bool vec3_reg_geometry_ok(int64_t n_file, int64_t sub_cells) {
     if (n_sub * n_file * n_file * 12 >= 0xfff00000ll) return false;
     return vec3_reg_recs(n_file, sub_cells) < (1ll << 26);
 }
-int encode_reg_vec3_blocks_per_cu(bool deep) {
-    if (!deep) { int m = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_encode_reg_vec3<false>, 256, 0) != hipSuccess) return 0; return m; }
+int encode_reg_vec3_blocks_per_cu(int depth) {
+    if (depth == 3) { int m = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_encode_reg_vec3<3>, 256, 0) != hipSuccess) return 0; return m; }
+    if (depth == 4) { int m = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_encode_reg_vec3<4>, 256, 0) != hipSuccess) return 0; return m; }
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_vec3<true>, 256, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_reg_vec3<5>, 256, 0) != hipSuccess) return 0;
     return n;
 }
 void launch_encode_reg_vec3(hipStream_t s, int grid, const float* vec, int64_t n_file, int64_t sub_cells, const DevJob* jobs, void* recs,
-                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item, int weighted, bool deep) {
+                            uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int64_t drop_item, int weighted, int depth) {
     Vec3RegArgs ra;
     ra.a = make_vec3_args(vec, n_file, sub_cells);
     ra.recs = (ItemRec*)recs;
     ra.gen = gen; ra.abort_flag = abort_flag; ra.abort_host = abort_host; ra.drop_item = drop_item;
     ra.n_sweepers = (uint32_t)vec3_reg_sweepers();
-    ra.weighted = ((grid - (int)ra.n_sweepers) % 4 == 0 && weighted >= 0 && weighted <= kRoundTables) ? weighted : 0;
+    ra.weighted = ((grid - (int)ra.n_sweepers) % 3 == 0 && depth > 3 && weighted >= 0 && weighted <= kV3Tables) ? weighted : 0;     // (thirds: three workgroups per CU)
     ra.m_T = ra.a.tiles_per_sc > 1 ? (uint32_t)((1ull << 32) / ra.a.tiles_per_sc) + 1u : 0u;
-    if (deep) hipLaunchKernelGGL(k_encode_reg_vec3<true>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
-    else hipLaunchKernelGGL(k_encode_reg_vec3<false>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
+    if (depth >= 5) hipLaunchKernelGGL(k_encode_reg_vec3<5>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
+    else if (depth == 4) hipLaunchKernelGGL(k_encode_reg_vec3<4>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
+    else hipLaunchKernelGGL(k_encode_reg_vec3<3>, dim3(grid), dim3(256), 0, s, ra, jobs, meta);
 }
 int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
     const int64_t n_sub = n_file / sub_cells, n3 = n_sub * n_sub * n_sub;
