@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--two-pass", action="store_true", help="disable the single-read encode (diagnostic)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-stream-ceiling", action="store_true", help="do not run tools/microbench/rw_mix first (profiler passes)")
     p.add_argument("--group-bytes", type=int, default=0)
     p.add_argument("--fused", action="store_true", help="float encode as one persistent launch (opt-in)")
     p.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: rehearsal of the "
@@ -519,6 +520,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # a bare stream of the codec's traffic mix on this GPU, as a child process BEFORE this process touches the GPU
+    ceiling = stream_ceiling() if (world == 1 and rank == 0 and not a.no_stream_ceiling) else None
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -560,8 +563,6 @@ def main():
     if a.two_pass:
         ctx.set_option("single_read", 0)
     timing = not a.no_kernel_timing
-    ceiling = stream_ceiling() if (world == 1 and rank == 0) else None      # (a child process on this GPU, before anything is timed)
-
     r = run_config(mnw, shard, ctx, x, y, device, dist, N, B, pixels, a.steps, a.warmup, timing, block0=b_lo, cdev=cdev)
 
     # ---- what a writer does with the ranks' results: (min, bits, nbytes) of every block gathered in block order,

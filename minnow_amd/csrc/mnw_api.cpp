@@ -1983,7 +1983,7 @@ int text_load(mnw_ctx* c, const uint8_t* text, int64_t nbytes, uint8_t sep, uint
         rc = ensure_dev(c, &c->d_text, &c->cap_text, (size_t)nbytes + 64);
         if (rc) return rc;
     }
-    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 16);
+    rc = ensure_dev(c, &c->d_tile, &c->cap_tile, (size_t)tiles * 16 + 32 + (size_t)((tiles + 1023) / 1024 + 1) * 16);     // counters, then the scan's chunk totals
     if (rc) return rc;
     if (!c->d_tslow) { HIPCHK(c, hipMalloc(&c->d_tslow, sizeof(mnw::TextSlow) * kTextSlowCap0)); c->cap_tslow = kTextSlowCap0; }
     if (!c->d_tstate) HIPCHK(c, hipMalloc(&c->d_tstate, sizeof(mnw::TextState)));

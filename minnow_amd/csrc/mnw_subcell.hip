@@ -1102,7 +1102,8 @@ __device__ __forceinline__ void v3_load_words(u32x2 (&w)[NW], const StreamView& 
     const int64_t w0 = (int64_t)t * (kVTile / 64) * b;
     int64_t left = sv.last + 1 - w0;                             // words of the stream from w0 on
     if (left < 0 || b == 0) left = 0;
-    if (left > NW * 256) left = NW * 256;
+    const int64_t nw = kVTile / 64 * (int64_t)b + 2;            // words that hold the vtile's bits (one look-ahead word, one for a stream that starts inside a word)
+    if (left > nw) left = nw;                                    // (lanes past them are out of range: no request -- not the next vtile's words)
     const __amdgpu_buffer_rsrc_t r = v3_rsrc(sv.a + w0, (uint32_t)left * 8u);
 #pragma unroll
     for (int k = 0; k < NW; ++k) w[k] = __builtin_amdgcn_raw_buffer_load_b64(r, (k * 256 + tid) * 8, 0, 0);

@@ -6,9 +6,9 @@ root=$(pwd)
 out=$root/gpurun_out/prof_minp_$tag
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/bench_minp.py --reps 5 > $out/bench_stats.json 2> $out/bench_stats.err || exit 1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 tools/bench_minp.py --reps 2 > $out/bench_fetch.json 2> $out/bench_fetch.err || exit 1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 tools/bench_minp.py --reps 2 > $out/bench_write.json 2> $out/bench_write.err || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 tools/bench_minp.py --reps 5 > $out/bench_stats.json 2> $out/bench_stats.err || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 tools/bench_minp.py --reps 2 > $out/bench_fetch.json 2> $out/bench_fetch.err || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 tools/bench_minp.py --reps 2 > $out/bench_write.json 2> $out/bench_write.err || exit 1
 python3 - $out <<'PY'
 import csv, glob, os, sys, collections, json
 out = sys.argv[1]
