@@ -442,25 +442,26 @@ __global__ __launch_bounds__(256, 4) void k_pack_vec3(Vec3Args a, const DevJob* 
 //     where the float statistics took 12.  The float64-multiply quotient (k_pack_f32's header) needs no per-element guard for
 //     the denormal range: a quotient down there quantizes to 0 or -1, so a wave whose minimum is <= 0 reloads its floats and
 //     redoes that component with the IEEE division (rare: only vtiles that touch the bottom of the range).
-//   * ONE workgroup per sub-cell derives its three descriptors: the one that holds the sub-cell's last vtile sweeps the
-//     sub-cell's 3 T item records a trip after it published its own, and publishes three 16-byte descriptor records; everybody
-//     else reads 16 bytes per component and trip instead of folding records.
-//   * Three items per workgroup as before (a record that is read must be a trip old): F, floats in flight for the next trip;
-//     Q, the pixel indices of the item quantized in this trip (registers; the quantization moves F to Q, so nothing is copied);
-//     and the OLD item, parked in LDS as three planes in the pack core's staging layout.
-// Per trip:   1. waves 0..2 pack OLD's component w from its plane with the descriptor requested a trip ago and store the words
-//                (wave-local); wave 3 does the sweep duty if the item in Q is its sub-cell's last
-//             barrier -- 2. Q -> planes  3. F (arrived) -> quantize -> Q, lane statistics, wave reduction -> LDS
+//   * ONE workgroup per sub-cell derives its three descriptors, and it is none of those that hold items: the last n_sweepers
+//     workgroups of the grid are sweepers (below).  Everybody else reads 16 bytes per component and trip instead of folding records.
+//   * DEPTH items per workgroup (a record that is read must be at least a trip old; with one sweep per sub-cell, two): F, floats
+//     in flight for the next trip; Q, the pixel indices of the item quantized in this trip (registers; the quantization moves F
+//     to Q, so nothing is copied); P (DEPTH >= 4) the item of the trip before; and the OLD item, parked in LDS as three planes in
+//     the pack core's staging layout.
+// Per trip:   1. waves 0..2 pack OLD's component w from its plane with the descriptor requested a trip ago (polling for it if it
+//                is not there yet) and store the words (wave-local)
+//             barrier -- 2. P (or Q) -> planes  3. F (arrived) -> quantize -> Q, lane statistics, wave reduction -> LDS
 //                        4. request the descriptor of the sub-cell now in the planes, then the next item's floats -> F
 //             barrier -- 5. wave 3 publishes the item's three records
 // vmcnt (see k_unpack_vec3): every wave issues the SAME vector-memory instructions every trip -- eight 16-byte stores and one
 // byte store of packed words, one descriptor load, six loads of floats, one record store -- as unconditional raw-buffer
 // operations whose idle lanes (or whole idle waves) carry an out-of-range offset, so that the compiler's counted waits let the
 // stores of a trip stay in flight under the loads that were issued before them.
-// No deadlock (blocks of at most G vtiles, all G workgroups resident): a workgroup publishes item i before it needs anything
-// that depends on item i, the descriptor of a sub-cell needs item records only, and the workgroup that derives it reaches
-// that trip once the descriptors of its earlier items are out, which are earlier sub-cells -- induction over the sub-cells in
-// order.  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the call through
+// No deadlock (blocks of at most G vtiles, all workgroups resident): a workgroup publishes item i before it needs anything
+// that depends on item i; a sweeper needs item records only and waits for nothing else; an item workgroup reaches the trip
+// that publishes an item of sub-cell s once the descriptors of its earlier items are out, which belong to sub-cells <= s whose
+// records were all published at least a trip earlier -- induction over the sub-cells in order (a sweeper takes its sub-cells in
+// increasing order too).  Waits are bounded (poll_abort): on expiry the launch gives up and the host reruns the call through
 // k_reduce_vec3 + k_pack_vec3.   HBM traffic = algorithmic: 12 B/particle read + the streams (+ 96 B of records per item).
 // ------------------------------------------------------------------------------------------------
 // Round sizes of k_encode_reg_vec3's weighted hand-out, in THIRDS of the grid (three workgroups per CU: a CU's three come from the
@@ -599,8 +600,9 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
     const uint32_t desc_off0 = n_item_recs * 32u;
 
     // ---- sweepers: the last ra.n_sweepers workgroups of the grid hold no items.  Sweeper j derives the descriptors of the sub-cells
-    // j, j + n_sweepers, ...: it waits for the sub-cell's last record, folds the 3 T item records (all four waves; again until none
-    // is missing), and lanes 0..2 of wave 3 decide and publish the three descriptor records and the blocks' metadata.  Nobody's
+    // j, j + n_sweepers, ...: it waits for the sub-cell's last record, folds the 3 T item records (all four waves, 512 records per
+    // batch of loads; again until none is missing), and lanes 0..2 of wave 3 decide and publish the three descriptor records and the
+    // blocks' metadata.  Nobody's
     // pipeline stands still for this: when the workgroup that holds a sub-cell's last vtile did it, its sweep -- two dependent
     // round trips and a wait for the slowest of 489 workgroups -- made it the straggler of the next rounds, whose own records
     // the next sub-cells' owners then waited for: every round paid for a sweep (measured: 80 % of the descriptor requests came
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
     lds_barrier();
 
     while (have_n || have_q || have_p || have_w || have_o) {
-        // ---- 1. pack the parked item (waves 0..2) | sweep duty (wave 3) ---------------------------------------------------------
+        // ---- 1. pack the parked item (waves 0..2; wave 3 issues the same, idle, memory instructions) ---------------------------
         {
             // (all waves run the same vector-memory instructions: eight chunk stores and one tail store; wave 3's are out of range)
             // (lane-specific addresses are built from an opaque lane number inside the trip: hoisted out of the loop they are kept,
