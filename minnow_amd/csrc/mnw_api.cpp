@@ -57,7 +57,7 @@ int vec3_reg_sweepers();
 bool vec3_reg_geometry_ok(int64_t, int64_t);
 int encode_reg_vec3_blocks_per_cu(int);
 void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t, int, int);
-void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float, int, bool, int);
+void launch_unpack_vec3(hipStream_t, int, float*, int64_t, int64_t, const DevJob*, int, float, int, bool, int, int);
 bool vec3_unpack_geometry_ok(int64_t, int64_t);
 constexpr int kMinhBatch = 64;
 struct MinhCol { const float* src; float* dst; int64_t n; float low, high, high_below; int32_t xform; };
@@ -288,7 +288,8 @@ struct mnw_ctx {
     int sr_backoff = 0, sr_backoff_left = 0;
     int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
-    int vec3_x_order = 1;        // minp vector kernels: workgroups in dispatch order take the sub-cells of one x-row together
+    int vec3_unpack_tiles = 8;   // minp decode: vtiles per workgroup of k_unpack_vec3 with vec3_x_order (505 us at 8 against 521-536 at 4 and 529 at 16)
+    int vec3_x_order = 2;        // minp decode: 1 = workgroups in dispatch order take the sub-cells of one x-row together; 2 = ... the workgroups of one XCD do (one L2 sees a whole row of the grid)
     int vec3_unpack_db = 1;      // k_unpack_vec3: two LDS word buffers and one barrier per vtile (0: one buffer, two barriers, more workgroups per CU)
     int vec3_deep = 4;           // k_encode_reg_vec3: items per workgroup between a vtile's publication and its pack (3: four workgroups per CU; 4, 5: three)
     int vec3_round_table = 4;    // k_encode_reg_vec3 (depth 4, 5): 0 = every round a whole grid, k > 0 = weighted hand-out by thirds of the grid, table k - 1 (4: 10 / 9 / 8 items per cycle)
@@ -1225,7 +1226,8 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_deep")) { c->vec3_deep = value < 3 ? 3 : value > 5 ? 5 : (int)value; c->reg_vec3_blocks_per_cu = 0; return MNW_OK; }
     if (!strcmp(name, "vec3_round_table")) { c->vec3_round_table = (int)value; return MNW_OK; }
-    if (!strcmp(name, "vec3_x_order")) { c->vec3_x_order = value != 0; return MNW_OK; }
+    if (!strcmp(name, "vec3_unpack_tiles")) { if (value < 1 || value > 1024) return MNW_E_ARG; c->vec3_unpack_tiles = (int)value; return MNW_OK; }
+    if (!strcmp(name, "vec3_x_order")) { if (value < 0 || value > 2) return MNW_E_ARG; c->vec3_x_order = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_db")) { c->vec3_unpack_db = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_weighted")) { c->reg_weighted = value != 0; return MNW_OK; }
     if (!strcmp(name, "reg_test_drop_item")) { c->reg_drop_item = value; return MNW_OK; }
@@ -1807,7 +1809,7 @@ int mnw_vectors_decode(mnw_ctx* c, mnw_stream_t stream, const uint8_t* src, int6
         int64_t gl = c->vec3_tiles_per_wg > 0 ? (vt + c->vec3_tiles_per_wg - 1) / c->vec3_tiles_per_wg : (int64_t)c->cus * 8;
         int g = (int)(gl > vt ? vt : gl);
         { ScopedTimer t(c, s, MNW_K_UNPACK_VEC3); mnw::launch_unpack_vec3(s, g, vec_out, n_file, sub_cells, sl->d_jobs, periodic != 0, L, max_bits, c->vec3_unpack_db != 0,
-                                                                                   c->vec3_x_order && c->vec3_tiles_per_wg > 0 ? c->vec3_tiles_per_wg : 0); }
+                                                                                   c->vec3_x_order ? c->vec3_unpack_tiles : 0, c->vec3_x_order >= 2); }
         HIPCHK(c, hipGetLastError());
         return release_slot(c, sl, s);
     }

@@ -1113,19 +1113,28 @@ __device__ __forceinline__ void v3_load_words(u32x2 (&w)[NW], const StreamView& 
 
 template <int NW, bool DB>
 __global__ __launch_bounds__(256) void k_unpack_vec3(Vec3Args a, float* __restrict__ vec_out, const DevJob* __restrict__ jobs,
-                                                     int periodic, float L, int tiles_per_wg) {
+                                                     int periodic, float L, int tiles_per_wg, int xcd_order) {
     static_assert(kTileD == kVTile, "the stream helpers are written for 2,048-element tiles");
     constexpr int kLW = NW * 256;                                       // 64-bit words of one component's buffer
     extern __shared__ __attribute__((aligned(16))) uint64_t v3_lds[];    // [1 or 2 buffers][3 components][kLW], then the images
     const SubcellGeom& gm = a.gm;
     int64_t v0, v1;
     if (tiles_per_wg > 0) {
-        // Workgroups in dispatch order walk the sub-cells of one x-row together (sx fastest): the five row segments that make up
-        // one row of the grid are then written at about the same time.  A sub-cell at a time leaves 1,200 of every 6,000 bytes
-        // of the grid's rows to each of five sub-cells processed one after the other, and rows written with such gaps move at
-        // 2.9 TB/s where contiguous ones move at 6.9 (tools/microbench/rw_mix.hip).
+        // The five row segments that make up one row of the grid are written at about the same time AND through the same L2: a
+        // sub-cell's rows are 1,200 of every 6,000 bytes of the grid's rows, their ends fall inside 64-byte granules that the
+        // neighbouring sub-cell's rows complete, and a granule that leaves an L2 half written costs the memory side a
+        // read-modify-write (tools/microbench/rows_order.hip, nothing but the stores of this kernel: 459 us sub-cell by sub-cell,
+        // 451 us with the x-neighbours adjacent in dispatch order -- workgroup w runs on XCD w mod 8, so they were in five
+        // different L2s --, 333-349 us with the x-neighbours on one XCD, 264 us for whole rows).  xcd_order: workgroup w is the
+        // (w / 8)-th of XCD w mod 8; consecutive workgroups of an XCD take the sub-cells of one x-row (sx fastest).
         const uint32_t S = gm.sub_cells, tq_n = (a.tiles_per_sc + tiles_per_wg - 1) / tiles_per_wg;
-        const uint32_t w = blockIdx.x, sx = w % S, q = w / S, tq = q % tq_n, syz = q / tq_n;
+        uint32_t sx, q;
+        if (xcd_order) {
+            const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            sx = slot % S; q = (slot / S) * 8 + xcd;
+            if (q >= tq_n * (a.s3 / S)) return;                        // (the grid is rounded up to whole groups of 8 S workgroups)
+        } else { sx = blockIdx.x % S; q = blockIdx.x / S; }
+        const uint32_t tq = q % tq_n, syz = q / tq_n;
         const uint32_t t0 = tq * tiles_per_wg, t1 = min(t0 + (uint32_t)tiles_per_wg, a.tiles_per_sc);
         v0 = (int64_t)(sx + S * syz) * a.tiles_per_sc + t0;
         v1 = v0 + (t1 - t0);
@@ -1305,15 +1314,18 @@ int64_t vec3_tiles(int64_t n_file, int64_t sub_cells) {
 // buffers and one barrier per vtile instead of one and two
 // tiles_per_wg > 0: x-interleaved order, the grid is sub_cells^3 * ceil(T / tiles_per_wg) workgroups (`grid` is ignored)
 void launch_unpack_vec3(hipStream_t s, int grid, float* vec_out, int64_t n_file, int64_t sub_cells, const DevJob* jobs, int periodic, float L,
-                        int max_bits, bool double_buffer, int tiles_per_wg) {
+                        int max_bits, bool double_buffer, int tiles_per_wg, int xcd_order) {
     const Vec3Args a = make_vec3_args(vec_out, n_file, sub_cells);
-    if (tiles_per_wg > 0) grid = (int)(a.s3 * ((a.tiles_per_sc + tiles_per_wg - 1) / tiles_per_wg));
+    if (tiles_per_wg > 0) {
+        const int64_t q_n = (int64_t)(a.s3 / a.gm.sub_cells) * ((a.tiles_per_sc + tiles_per_wg - 1) / tiles_per_wg);     // pieces per sub-cell of an x-row
+        grid = (int)(xcd_order ? (q_n + 7) / 8 * 8 * a.gm.sub_cells : q_n * a.gm.sub_cells);
+    }
     if (max_bits < 1) max_bits = 1;
     const int words = kVTile / 64 * max_bits + 2;                 // 64-bit words of one component's vtile
     const int nw = words <= 2 * 256 ? 2 : words <= 3 * 256 ? 3 : 5;
     const size_t lds = (size_t)(double_buffer ? 2 : 1) * 3 * nw * 256 * sizeof(uint64_t) + (size_t)4 * kV3ImgDw * sizeof(uint32_t);
-#define MNW_LAUNCH_UV3(NWV) do { if (double_buffer) hipLaunchKernelGGL((k_unpack_vec3<NWV, true>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg); \
-                                 else hipLaunchKernelGGL((k_unpack_vec3<NWV, false>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg); } while (0)
+#define MNW_LAUNCH_UV3(NWV) do { if (double_buffer) hipLaunchKernelGGL((k_unpack_vec3<NWV, true>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg, xcd_order); \
+                                 else hipLaunchKernelGGL((k_unpack_vec3<NWV, false>), dim3(grid), dim3(256), lds, s, a, vec_out, jobs, periodic, L, tiles_per_wg, xcd_order); } while (0)
     if (nw == 2) MNW_LAUNCH_UV3(2);
     else if (nw == 3) MNW_LAUNCH_UV3(3);
     else MNW_LAUNCH_UV3(5);

@@ -234,6 +234,28 @@ def test_vectors_fused_and_staged_paths_agree_with_oracle(mnw, oracle, torch_mod
             assert host[b * slot: b * slot + m.nbytes].tobytes() == odata.tobytes(), b
 
 
+@pytest.mark.parametrize("x_order,tiles", [(0, 8), (1, 1), (1, 4), (2, 1), (2, 3), (2, 8), (2, 64)])
+@pytest.mark.parametrize("nf,sub_cells", [(48, 2), (60, 3), (80, 5)])
+def test_vectors_decode_orderings_agree_with_oracle(mnw, oracle, torch_mod, x_order, tiles, nf, sub_cells):
+    """k_unpack_vec3's work distribution (vec3_x_order 0: contiguous ranges; 1: x-neighbours adjacent in dispatch order; 2, the
+    default: x-neighbours on one XCD, grid rounded up to groups of 8 * sub_cells workgroups of which the surplus exits at once)
+    and pieces of 1 .. more-than-a-sub-cell vtiles: every combination decodes the oracle's floats, sub-cell counts that are not
+    multiples of eight and partial last vtiles included (13,824 / 8,000 / 4,096 particles per sub-cell)."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5 + nf)
+    L = 250.0
+    g = make_vectors((0, 0, 0), L, nf)
+    pos = np.mod(g + 3.0 * rng.standard_normal(g.shape), L).astype(np.float32)
+    pos[pos >= np.float32(L)] = 0.0
+    with mnw.Context(0) as c:
+        c.set_option("vec3_x_order", x_order)
+        c.set_option("vec3_unpack_tiles", tiles)
+        c.timing_enable(True)
+        _roundtrip(mnw, c, oracle, torch, dev, np.ascontiguousarray(pos), nf, sub_cells, 0.001, True, L)
+        assert c.timing_get()["k_unpack_vec3"]["launches"] >= 1
+
+
 def test_vectors_host_pointer_forms(mnw, oracle):
     """mnw_vectors_encode_host / _decode_host: numpy arrays standing in for the Go slices of minp.Writer.Vectors"""
     import ctypes as C
