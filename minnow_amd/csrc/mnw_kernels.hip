@@ -1234,7 +1234,10 @@ __constant__ int kRoundTable[kRoundTables][kMaxRounds] = {
 // BIG: the batch has blocks of more than kMaxSweep items (two-level sweep: group_duty_f32, block_desc_big_f32).  Also an instantiation of its
 // own: the extra call site costs the plain kernel scratch traffic on its critical path.
 template <bool XF, bool BIG>
-__global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
+#ifndef MNW_XF_WGS
+#define MNW_XF_WGS 3      // workgroups per CU of the instantiations with the minh value transform: at four they spill 38 registers (6.8 against 6.1 ms for the 24 float columns of tools/bench_c3.py --minh)
+#endif
+__global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f32(const DevJob* __restrict__ jobs, int njobs,
                                                                  int64_t total_items, const int* __restrict__ item_job,
                                                                  ItemRec* __restrict__ recs, ItemRec* __restrict__ grecs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
