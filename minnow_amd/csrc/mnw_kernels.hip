@@ -2107,6 +2107,8 @@ __device__ __forceinline__ uint64_t extract64(const uint64_t* __restrict__ l64, 
 // (go/minh/minh.go:315-319; DevJob.xform & kXfLog10), applied to the decoded value before it is stored -- the column is
 // written once, not written, read back and written again by a pass of its own.  An instantiation of its own (2.5 KB of
 // tables in LDS, float64 arithmetic): the plain kernel is not touched.
+// (the XF instantiation needs 124 registers, four waves per SIMD; bounded to five, six or eight waves it spills and takes 7.8, 10.5,
+// 14.1 ms where this takes 5.3 for the 24 float columns of tools/bench_c3.py --minh)
 template <bool NARROW, bool XF>
 __global__ __launch_bounds__(kThreads) void k_unpack_f32(const DevJob* __restrict__ jobs, int njobs,
                                                          int64_t total_tiles) {
