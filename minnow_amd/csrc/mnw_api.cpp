@@ -33,9 +33,10 @@ void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
 void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int, int);
-void launch_encode_reg_i64(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t);
+void launch_encode_reg_i64(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, void*, int, int);
 int64_t reg_item_elems_i64();
 int encode_reg_i64_blocks_per_cu();
+int encode_reg_i64_sweepers();
 size_t item_rec_bytes();
 int reg_max_items_per_block();
 int reg_max_items_per_big_block();
@@ -288,6 +289,7 @@ struct mnw_ctx {
     int sr_backoff = 0, sr_backoff_left = 0;
     int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
+    int int_flat_items = 256;    // int64 blocks of more items (of 4,096) get their descriptor from the sweeper workgroups of k_encode_reg_i64 (2^21-element blocks: 0.60 of 8 TB/s against 0.52 through the flat sweep of 512 records per workgroup and trip; at 256 items the two are equal)
     int vec3_unpack_tiles = 8;   // minp decode: vtiles per workgroup of k_unpack_vec3 with vec3_x_order (505 us at 8 against 521-536 at 4 and 529 at 16)
     int vec3_x_order = 2;        // minp decode: 1 = workgroups in dispatch order take the sub-cells of one x-row together; 2 = ... the workgroups of one XCD do (one L2 sees a whole row of the grid)
     int vec3_unpack_db = 1;      // k_unpack_vec3: two LDS word buffers and one barrier per vtile (0: one buffer, two barriers, more workgroups per CU)
@@ -931,11 +933,13 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         if (max_ni > lim) fl = false;
     }
     if (!fl) items = 0;
-    // ---- int jobs: flat sweep only
+    // ---- int jobs.  Blocks of at most min(G, 512) items: flat sweep.  Larger ones, up to 2 G items (2^23 elements on a full grid):
+    // sweeper workgroups at the end of the grid derive their descriptors, rounds unweighted (k_encode_reg_i64's header).
     const int64_t item_i = mnw::reg_item_elems_i64();
     int grid_i = c->cus * c->reg_i64_blocks_per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid_i) grid_i = c->grid_cap;
     int64_t items_i = 0;
+    int nsw_i = 0, flat_i = 0;
     bool in = c->single_read_int && nslot_all > nfloat && c->reg_i64_blocks_per_cu >= 1;
     if (in) {
         int64_t mx = 0;
@@ -944,9 +948,18 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
             if (ni > mx) mx = ni;
             items_i += ni;
         }
+        const int full = grid_i;
         if (items_i < grid_i) grid_i = items_i > 0 ? (int)items_i : 1;
-        const int64_t flat = mnw::reg_max_items_per_block();
-        if (mx > (grid_i < flat ? grid_i : flat)) in = false;
+        const int64_t flat = c->big_blocks && c->int_flat_items < mnw::reg_max_items_per_block() ? c->int_flat_items : mnw::reg_max_items_per_block();
+        flat_i = (int)(grid_i < flat ? grid_i : flat);
+        if (mx > flat_i) {
+            // item workgroups + sweepers must all be resident: the sweepers come out of the full grid
+            nsw_i = mnw::encode_reg_i64_sweepers();
+            const int gi = full - nsw_i < items_i ? full - nsw_i : (int)items_i;
+            flat_i = (int)(gi < flat ? gi : flat);
+            if (!c->big_blocks || gi < 1 || mx > 2 * (int64_t)gi) { in = false; nsw_i = 0; }
+            else grid_i = gi + nsw_i;
+        }
     }
     if (!in) items_i = 0;
     if (!fl && !in) return MNW_OK;
@@ -969,7 +982,7 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         int64_t t = 0;
         for (int k = nfloat; k < nslot_all; ++k) { sl->h_jobs[k].tile0 = t; t += (sl->h_jobs[k].n + item_i - 1) / item_i; }
     }
-    const size_t need = (size_t)(items + groups + items_i) * mnw::item_rec_bytes();
+    const size_t need = (size_t)(items + groups + items_i + (nsw_i ? nslot_all - nfloat : 0)) * mnw::item_rec_bytes();      // (+ one descriptor record per int job)
     if (need > c->cap_recs) {
         // (re)allocation happens between batches only: the previous batch has been finished by then
         if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
@@ -1031,7 +1044,8 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_I64);
         mnw::launch_encode_reg_i64(s, grid_i, sl->d_jobs + nfloat, nslot_all - nfloat, items_i, sl->d_itemjob + items_pad,
                                    (uint8_t*)c->d_recs + (size_t)(items + groups) * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl),
-                                   sl->d_hsync, sl->d_meta + nfloat, (grid_i == c->cus * 4 && c->reg_weighted) ? 1 + c->reg_round_table : 0, c->reg_drop_item);
+                                   sl->d_hsync, sl->d_meta + nfloat, (grid_i == c->cus * 4 && c->reg_weighted && nsw_i == 0) ? 1 + c->reg_round_table : 0, c->reg_drop_item,
+                                   (uint8_t*)c->d_recs + (size_t)(items + groups + items_i) * mnw::item_rec_bytes(), nsw_i, flat_i);
     }
     HIPCHK(c, hipGetLastError());
     *did_float = fl; *did_int = in;
@@ -1226,6 +1240,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_deep")) { c->vec3_deep = value < 3 ? 3 : value > 5 ? 5 : (int)value; c->reg_vec3_blocks_per_cu = 0; return MNW_OK; }
     if (!strcmp(name, "vec3_round_table")) { c->vec3_round_table = (int)value; return MNW_OK; }
+    if (!strcmp(name, "int_flat_items")) { if (value < 1) return MNW_E_ARG; c->int_flat_items = (int)(value > 512 ? 512 : value); return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_tiles")) { if (value < 1 || value > 1024) return MNW_E_ARG; c->vec3_unpack_tiles = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_x_order")) { if (value < 0 || value > 2) return MNW_E_ARG; c->vec3_x_order = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_db")) { c->vec3_unpack_db = value != 0; return MNW_OK; }

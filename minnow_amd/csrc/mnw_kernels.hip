@@ -1623,7 +1623,14 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
 // A record = the item's max and min as four self-validating words {high half, tag} {low half, tag} (max), (min); a block's
 // statistics are the 64-bit max / min over its records.  Widths above 32 bits (a block whose values span more than 2^32)
 // are packed in place in the LDS stage (pack_group64_inplace).  Blocks of at most min(G, 512) items (2^21 elements): flat
-// sweep only; anything larger, and explicit-mode jobs (raw bit arrays), stay on k_reduce_i64 + k_pack_i64.
+// sweep -- every workgroup folds the records of its parked item's block itself.  Larger blocks, up to 2 G items (2^23 elements
+// = 64 MB on a whole MI355X: what two items per workgroup hold), round 3: the last `n_sweepers` workgroups of the grid hold no
+// items; sweeper s takes the large jobs j = s (mod n_sweepers) in order, waits for the block's last record, folds all of them and
+// publishes ONE descriptor record per block (k_encode_reg_vec3's arrangement), which the item workgroups read instead of
+// sweeping.  No deadlock: rounds are unweighted (a workgroup's items are G apart, at most two of them in a block), a workgroup
+// publishes its current item before it waits for its parked item's descriptor, so whoever waits has published everything it
+// holds of that block; a sweeper waits for item records only; induction over the blocks in order, as in k_encode_reg_f32.
+// Anything larger, and explicit-mode jobs (raw bit arrays), stay on k_reduce_i64 + k_pack_i64.
 // ------------------------------------------------------------------------------------------------
 constexpr int kItemI = 4096;                        // int64 elements per item (32 KB, like a float item)
 constexpr int kBufI = (kItemI / kGroup) * kStride64;      // dwords of the parked item: 128 groups x 68 dwords = 34,816 B
@@ -1703,7 +1710,8 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
                                                                  const int* __restrict__ item_job, ItemRec* __restrict__ recs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
                                                                  uint32_t* __restrict__ abort_host, Meta* __restrict__ meta, int weighted,
-                                                                 int64_t drop_item) {
+                                                                 int64_t drop_item, ItemRec* __restrict__ drecs, int n_sweepers, int flat_lim) {
+    // (drecs: one descriptor record per job, for blocks of more than flat_lim items; n_sweepers = 0 if the launch has none)
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufI];
     __shared__ int64_t red[2][kThreadsR / 64];
     __shared__ int64_t swr[2][kThreadsR / 64];
@@ -1730,7 +1738,88 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
             for (int k = 0; k < kV; ++k) e[k] = ldg<u32x4>(cx + cbase + k * (2 * kThreadsR) + 2 * t);
         }
     };
-    const int unit = weighted ? (int)gridDim.x / 4 : (int)gridDim.x;
+    const int G = (int)gridDim.x - n_sweepers;          // workgroups that hold items
+    if (tid == 0) abort_s = 0;
+    if ((int)blockIdx.x >= G) {
+        // ---- sweeper: the descriptors of the large blocks j = s (mod n_sweepers), in job order
+        const int s_id = (int)blockIdx.x - G;
+        int seen = 0;                                    // large jobs before j0 (uniform)
+        lds_barrier();
+        for (int j0 = 0; j0 < njobs; j0 += kThreadsR) {
+            const int jt = j0 + tid;
+            const bool big = jt < njobs && items_of_i(jobs[jt].n) > flat_lim;
+            // the large jobs of this stretch, in order, through LDS (one flag per thread)
+            reinterpret_cast<uint8_t*>(lds)[tid] = big ? 1 : 0;
+            lds_barrier();
+            for (int q = 0; q < kThreadsR && j0 + q < njobs; ++q) {
+                if (!reinterpret_cast<const uint8_t*>(lds)[q]) continue;
+                const bool mine = seen % n_sweepers == s_id;
+                ++seen;
+                if (!mine) continue;
+                const int j = j0 + q;
+                const DevJob jb = jobs[j];
+                const int T = (int)items_of_i(jb.n);
+                const ItemRec* r0 = recs + jb.tile0;
+                uint32_t spins = 0;
+                const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                // a hint that the block is (nearly) complete: its last record
+                for (;;) {
+                    uint64_t w[4];
+                    load_rec_sc1(r0 + (T - 1), w);
+                    if ((uint32_t)(w[3] >> 32) == gen) break;
+                    if (poll_abort(spins, t_start, abort_flag, abort_host)) { if (lane_id() == 0) abort_s = 1; break; }
+                }
+                lds_barrier();
+                if (abort_s) return;
+                for (;;) {
+                    int64_t vmax = INT64_MIN, vmin = INT64_MAX;
+                    uint32_t missing = 0;
+                    for (int r = tid; r < T; r += kThreadsR) {
+                        uint64_t w[4];
+                        load_rec_sc1(r0 + r, w);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) missing |= (uint32_t)(w[k] >> 32) != gen;
+                        const int64_t a = (int64_t)(((uint64_t)(uint32_t)w[0] << 32) | (uint32_t)w[1]);
+                        const int64_t b = (int64_t)(((uint64_t)(uint32_t)w[2] << 32) | (uint32_t)w[3]);
+                        vmax = a > vmax ? a : vmax; vmin = b < vmin ? b : vmin;
+                    }
+                    vmax = wave_max_i64(vmax); vmin = wave_min_i64(vmin);
+                    const int miss = __any(missing);
+                    if (lane_id() == 0) { swr[0][wave_id()] = vmax; swr[1][wave_id()] = vmin; swm[wave_id()] = miss; }
+                    lds_barrier();
+                    int64_t bmx = swr[0][0], bmn = swr[1][0];
+                    int anymiss = swm[0];
+#pragma unroll
+                    for (int w = 1; w < kW; ++w) { bmx = swr[0][w] > bmx ? swr[0][w] : bmx; bmn = swr[1][w] < bmn ? swr[1][w] : bmn; anymiss |= swm[w]; }
+                    if (!anymiss) {
+                        if (tid < 4) {
+                            DescI d = {bmn, 0, 0, 0};
+                            d.bits = precision_needed((uint64_t)bmx - (uint64_t)bmn);           // group.go:246-248, bit.go:151-159
+                            if (d.bits < 0) { d.status = -6; d.bits = 0; }
+                            else {
+                                d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jb.n);
+                                if (d.nbytes > jb.cap) d.status = -5;
+                            }
+                            if (tid == 0) { Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status}; meta[j] = m; }
+                            // the record: {min high, min low, width | status code << 8, 0}, each word tagged
+                            const uint32_t code = d.status == 0 ? 0u : d.status == -5 ? 2u : 3u;
+                            const uint32_t val = tid == 0 ? (uint32_t)((uint64_t)d.imin >> 32) : tid == 1 ? (uint32_t)(uint64_t)d.imin
+                                               : tid == 2 ? ((uint32_t)d.bits | (code << 8)) : 0u;
+                            __hip_atomic_store(&drecs[j].g[tid], (uint64_t)val | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        lds_barrier();                   // (swr / swm are free again)
+                        break;
+                    }
+                    if (wave_id() == 0 && poll_abort(spins, t_start, abort_flag, abort_host) && lane_id() == 0) abort_s = 1;
+                    lds_barrier();
+                    if (abort_s) return;
+                }
+            }
+            lds_barrier();                               // (the flags are rewritten by the next stretch)
+        }
+        return;
+    }
+    const int unit = weighted ? G / 4 : G;
     int round = 0;
     int64_t round_base = 0;
     auto next_item = [&]() -> int64_t {
@@ -1747,7 +1836,6 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
     bool have_prev = false;
     int pj = 0;
     int64_t pbase = 0, pit = 0;
-    if (tid == 0) abort_s = 0;
 
     while (have_cur || have_prev) {
         const int sj = cj;
@@ -1762,11 +1850,13 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
         // published a trip ago); folded after the statistics of item i
         DevJob pjb;
         int pitems = 0;
+        bool pbig = false;                               // the parked item's block is a large one: its descriptor comes from a sweeper
         u32x4 swa, swb;
         if (have_prev) {
             pjb = jobs[pj];
             pitems = (int)items_of_i(pjb.n);
-            if (tid < pitems) rec_prefetch(recs + pjb.tile0, pitems, tid, swa, swb);     // (waves without a record skip the instructions)
+            pbig = pitems > flat_lim;
+            if (!pbig && tid < pitems) rec_prefetch(recs + pjb.tile0, pitems, tid, swa, swb);     // (waves without a record skip the instructions)
         }
 
         if (have_cur) {
@@ -1789,7 +1879,7 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
             mn = wave_min_i64(mn); mx = wave_max_i64(mx);
             if (lane_id() == 0) { red[0][wave_id()] = mx; red[1][wave_id()] = mn; }
         }
-        if (have_prev) {
+        if (have_prev && !pbig) {
             // fold what the record loads brought (blocks of more than 256 items: the second half follows)
             const bool mine = tid < pitems;
             uint32_t missing = mine && ((swa.y != gen) | (swa.w != gen) | (swb.y != gen) | (swb.w != gen));
@@ -1821,7 +1911,30 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
 
         if (have_prev) {
             // ---- 3. item i-1: the descriptor of its block (wave 0), then re-base and pack (lanes 0..127)
-            if (wave_id() == 0) {
+            if (wave_id() == 0 && pbig) {
+                // the block's descriptor record, published by a sweeper once the block's last record is out
+                uint32_t spins = 0;
+                const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                for (;;) {
+                    uint64_t w[4];
+                    load_rec_sc1(drecs + pj, w);
+                    if ((uint32_t)(w[0] >> 32) == gen && (uint32_t)(w[1] >> 32) == gen && (uint32_t)(w[2] >> 32) == gen && (uint32_t)(w[3] >> 32) == gen) {
+                        if (lane_id() == 0) {
+                            DescI d;
+                            d.imin = (int64_t)(((uint64_t)(uint32_t)w[0] << 32) | (uint32_t)w[1]);
+                            const uint32_t info = (uint32_t)w[2];
+                            d.bits = (int)(info & 0xffu);
+                            const uint32_t code = info >> 8;
+                            d.status = code == 0 ? 0 : code == 2 ? -5 : -6;
+                            d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, pjb.n);
+                            desc_s = d;
+                        }
+                        break;
+                    }
+                    if (poll_abort(spins, t_start, abort_flag, abort_host)) { if (lane_id() == 0) abort_s = 1; break; }
+                }
+            }
+            if (wave_id() == 0 && !pbig) {
                 int64_t bmx = swr[0][0], bmn = swr[1][0];
                 int miss = swm[0];
 #pragma unroll
@@ -2388,10 +2501,14 @@ void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njob
 #undef MNW_LAUNCH_REG
 }
 void launch_encode_reg_i64(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
-                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t drop_item) {
+                           uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted, int64_t drop_item,
+                           void* drecs, int n_sweepers, int flat_lim) {
+    // grid: the item workgroups AND the sweepers (the last n_sweepers; 0 when no block has more than flat_lim items)
     hipLaunchKernelGGL(k_encode_reg_i64, dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, (ItemRec*)recs, gen,
-                       abort_flag, abort_host, meta, (weighted > 0 && weighted <= kRoundTables && grid % 4 == 0) ? weighted : 0, drop_item);
+                       abort_flag, abort_host, meta, (weighted > 0 && weighted <= kRoundTables && n_sweepers == 0 && grid % 4 == 0) ? weighted : 0, drop_item,
+                       (ItemRec*)drecs, n_sweepers, flat_lim);
 }
+int encode_reg_i64_sweepers() { return 8; }
 int64_t reg_item_elems_i64() { return kItemI; }
 int encode_reg_i64_blocks_per_cu() {
     int n = 0;

@@ -616,17 +616,19 @@ def test_int_single_read_batch_bit_exact(mnw, oracle, torch_mod):
             for x, m, o, (omin, obits, odata) in zip(fl, fm, fouts, fwant):
                 assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0)
                 assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes()
-        # blocks beyond the sweep's reach (more than 512 items of 4,096) keep the two launches
+        # blocks beyond the flat sweep's reach (more than 512 items of 4,096): read once too, their descriptors come from the
+        # sweeper workgroups (round 3); next to a small block
         big = rng.integers(5, 2**27, size=2**21 + 4097, dtype=np.int64)
         tb = torch.from_numpy(big).to(dev)
         ob = torch.zeros(8 * big.size + 16, dtype=torch.uint8, device=dev)
         c2.timing_reset(); c2.counters_reset()
         m = c2.encode_blocks([mnw.EncJob(tb.data_ptr(), ob.data_ptr(), big.size, ob.numel(), mnw.INT_GROUP), ijobs[3]])
         torch.cuda.synchronize()
-        assert c2.counters()["int_single_read_batches"] == 0 and c2.timing_get()["k_pack_i64"]["launches"] >= 1
+        assert c2.counters()["int_single_read_batches"] == 1 and c2.timing_get()["k_pack_i64"]["launches"] == 0
         omin, obits, odata = oracle.int_encode(big, literal=False)
         assert (m[0].min, m[0].bits, m[0].nbytes) == (omin, obits, odata.size)
         assert ob[: m[0].nbytes].cpu().numpy().tobytes() == odata.tobytes()
+        assert (m[1].min, m[1].bits, m[1].nbytes) == (want[3][0], want[3][1], want[3][2].size)
         # the domain error (go/bit.go:19-21 with max - min = 2^64 - 1) and a capacity error, per block, next to good blocks
         bad = torch.tensor([-(2**63), 2**63 - 1, 5], dtype=torch.int64, device=dev)
         obad = torch.zeros(64, dtype=torch.uint8, device=dev)
@@ -640,6 +642,70 @@ def test_int_single_read_batch_bit_exact(mnw, oracle, torch_mod):
         assert int(small.max()) == 0 and int(obad.max()) == 0
         for k, mm in ((1, m[0]), (2, m[3])):
             assert outs[k][: mm.nbytes].cpu().numpy().tobytes() == want[k][2].tobytes()
+
+
+def test_int_large_blocks_read_once(mnw, oracle, torch_mod):
+    """int64 blocks of 2^21 .. 2^23 elements through k_encode_reg_i64 ONLY (descriptor records from its sweeper workgroups): a
+    batch of the largest block the chip holds (two items of 4,096 in each of the 1,024 - 8 item workgroups of an MI355X: 8,323,072
+    elements), a ragged 2^22 + 12,345 one of more than 32 bits,
+    a constant one, small blocks in between; bytes equal to the oracle's (go/group.go:242-255) and to the two-launch path's.
+    One element more than 2 x (item workgroups) x 4,096 keeps reduce + pack; so does big_blocks = 0; a record that never
+    appears makes the launch give up and the call is redone by the two launches."""
+    torch = torch_mod
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2023)
+    nmax = 2 * (1024 - 8) * 4096
+    xs = [rng.integers(-3, 2**19, size=nmax, dtype=np.int64),
+          rng.integers(7, 100, size=5000, dtype=np.int64),
+          rng.integers(-2**40, 2**41, size=2**22 + 12345, dtype=np.int64),
+          np.full(2**21 + 1, 123456789012, dtype=np.int64),
+          rng.integers(0, 2**31, size=2**20, dtype=np.int64)]
+    xs[0][-1] = 2**20 + 5          # the maximum in the block's last item, the minimum in its first
+    xs[0][0] = -77
+    want = [oracle.int_encode(x, literal=False) for x in xs]
+    with mnw.Context(0) as c2:
+        ts = [torch.from_numpy(x).to(dev) for x in xs]
+        outs = [torch.zeros(8 * x.size + 16, dtype=torch.uint8, device=dev) for x in xs]
+        jobs = [mnw.EncJob(t.data_ptr(), o.data_ptr(), t.numel(), o.numel(), mnw.INT_GROUP) for t, o in zip(ts, outs)]
+        torch.cuda.synchronize()
+        for mode in ("reg", "two_pass", "no_big", "reg", "drop"):
+            c2.set_option("single_read_int", 0 if mode == "two_pass" else 1)
+            c2.set_option("big_blocks", 0 if mode == "no_big" else 1)
+            c2.set_option("single_read_backoff", 0)
+            c2.set_option("reg_test_drop_item", 2032 + 2 + 700 if mode == "drop" else -1)      # an item of the third block
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            c2.timing_enable(True); c2.timing_reset(); c2.counters_reset()
+            metas = c2.encode_blocks(jobs)
+            torch.cuda.synchronize()
+            ran = {k for k, v in c2.timing_get().items() if v["launches"]}
+            cnt = c2.counters()
+            if mode == "reg":
+                assert "k_encode_reg_i64" in ran and "k_pack_i64" not in ran and "k_reduce_i64" not in ran, (mode, sorted(ran))
+                assert cnt["int_single_read_batches"] == 1 and cnt["single_read_aborts"] == 0
+            elif mode == "drop":
+                assert "k_encode_reg_i64" in ran and "k_pack_i64" in ran and cnt["single_read_aborts"] == 1, (sorted(ran), cnt)
+            else:
+                assert "k_encode_reg_i64" not in ran and "k_pack_i64" in ran, (mode, sorted(ran))
+            for x, m, o, (omin, obits, odata) in zip(xs, metas, outs, want):
+                assert (m.min, m.bits, m.nbytes, m.status) == (omin, obits, odata.size, 0), (mode, x.size, m.min, m.bits, omin, obits)
+                assert o[: m.nbytes].cpu().numpy().tobytes() == odata.tobytes(), (mode, x.size, obits)
+                assert int(o[m.nbytes:].max()) == 0
+        c2.set_option("reg_test_drop_item", -1)
+        # beyond what two items per workgroup hold: the two launches
+        del ts, outs
+        n = nmax + 1
+        huge = rng.integers(0, 1000, size=n, dtype=np.int64)
+        th = torch.from_numpy(huge).to(dev)
+        oh = torch.zeros(8 * n + 16, dtype=torch.uint8, device=dev)
+        c2.timing_reset(); c2.counters_reset()
+        m = c2.encode_blocks([mnw.EncJob(th.data_ptr(), oh.data_ptr(), n, oh.numel(), mnw.INT_GROUP)])
+        torch.cuda.synchronize()
+        assert c2.counters()["int_single_read_batches"] == 0 and c2.timing_get()["k_pack_i64"]["launches"] >= 1
+        omin, obits, odata = oracle.int_encode(huge, literal=False)
+        assert (m[0].min, m[0].bits, m[0].nbytes) == (omin, obits, odata.size)
+        assert oh[: m[0].nbytes].cpu().numpy().tobytes() == odata.tobytes()
 
 
 def test_int_single_read_abort_and_host_fallback(mnw, oracle, torch_mod):
