@@ -448,3 +448,14 @@ def test_vectors_single_read_shapes_and_give_up(mnw, oracle, torch_mod, nf, sub_
         torch.cuda.synchronize()
         check(metas)
         assert c.counters()["single_read_aborts"] == 1 and c.timing_get()["k_encode_reg_vec3"]["launches"] == 5
+
+
+def test_fuzz_short(mnw, oracle):
+    """a few seconds of tests/fuzz_minp.py: random file-cell geometries, value distributions, limits and library options (every depth
+    and hand-out table of the single-read kernel, the two-launch form, the staging path, every decode ordering) against the oracle;
+    the long runs are done by hand (`python tests/fuzz_minp.py 600 1`: profiles/r03/fuzz_minp.log)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import fuzz_minp
+    cases, blocks, single, staged = fuzz_minp.run(8.0, 2026)
+    assert cases >= 3 and single >= 1
