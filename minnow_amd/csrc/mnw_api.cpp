@@ -32,7 +32,8 @@ void launch_pack_f32(hipStream_t, int, const DevJob*, int, int64_t, void*);
 void launch_pack_i64(hipStream_t, int, const DevJob*, int, int64_t, const uint64_t*, Meta*);
 void launch_encode_f32(hipStream_t, int, const DevJob*, int, const int64_t*, const int*, int, uint64_t*, void*, uint32_t*, Meta*);
 int encode_f32_blocks_per_cu();
-void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int, int);
+void launch_encode_reg_f32(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, int, int, void*, int, int);
+int encode_reg_f32_sweepers();
 void launch_encode_reg_i64(hipStream_t, int, const DevJob*, int, int64_t, const int*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int, int64_t, void*, int, int);
 int64_t reg_item_elems_i64();
 int encode_reg_i64_blocks_per_cu();
@@ -289,6 +290,7 @@ struct mnw_ctx {
     int sr_backoff = 0, sr_backoff_left = 0;
     int reg_round_table = 0;     // which of the kernels' round tables the weighted hand-out uses (0 = 14/12/11/10; the others: measurements)
     int unlog_fused = 1;         // minh reader: 10^x applied inside k_unpack_f32 (one write of the column) rather than by k_minh_unlog afterwards
+    int float_flat_items = 512;  // float blocks of more items (of 8,192) get their descriptor from the sweeper workgroups of k_encode_reg_f32<., BIG>
     int int_flat_items = 256;    // int64 blocks of more items (of 4,096) get their descriptor from the sweeper workgroups of k_encode_reg_i64 (2^21-element blocks: 0.60 of 8 TB/s against 0.52 through the flat sweep of 512 records per workgroup and trip; at 256 items the two are equal)
     int vec3_unpack_tiles = 8;   // minp decode: vtiles per workgroup of k_unpack_vec3 with vec3_x_order (505 us at 8 against 521-536 at 4 and 529 at 16)
     int vec3_x_order = 2;        // minp decode: 1 = workgroups in dispatch order take the sub-cells of one x-row together; 2 = ... the workgroups of one XCD do (one L2 sees a whole row of the grid)
@@ -909,13 +911,16 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
     int any_xform = 0;
     for (int k = 0; k < nfloat; ++k) any_xform |= sl->h_jobs[k].xform;
     const int per_cu = any_xform ? c->reg_xf_blocks_per_cu : c->reg_blocks_per_cu;
-    // ---- float jobs.  Blocks of at most min(G, 512) items: flat record sweep, weighted hand-out.  Larger ones, up to
-    // min(2 G, 4096) items (2^24 elements on a full grid of G = 1,024): two-level sweep; beyond G items the rounds must be
-    // unweighted (see "large blocks" in mnw_kernels.hip).  `big_blocks` = 0 keeps everything above 512 items on two passes.
+    // ---- float jobs.  Blocks of at most min(G, 512) items: flat record sweep, weighted hand-out.  Larger ones (`big_blocks` = 0
+    // keeps them on two passes): more than `float_flat_items` (256) and at most 2 G' items, G' = G - 8 -- eight sweeper workgroups at
+    // the end of the grid derive their descriptors (round 3; 2^22-element blocks 0.55 -> 0.6x of 8 TB/s); up to min(2 G, 4096) items
+    // (2^24 elements on a full grid of G = 1,024, which leaves no workgroup over): the two-level sweep.  Beyond G' (G) items the
+    // rounds must be unweighted (see "large blocks" in mnw_kernels.hip).
     const int64_t item = mnw::reg_item_elems();
     int grid = c->cus * per_cu;
     if (c->grid_cap > 0 && c->grid_cap < grid) grid = c->grid_cap;
     int64_t items = 0, groups = 0, max_ni = 0;
+    int nsw_f = 0, flat_f = (int)mnw::reg_max_items_per_block();
     bool fl = want_float && nfloat > 0 && per_cu >= 1;
     if (fl) {
         for (int k = 0; k < nfloat; ++k) {
@@ -923,12 +928,20 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
             if (ni > max_ni) max_ni = ni;
             items += ni;
         }
+        const int full = grid;
         if (items < grid) grid = items > 0 ? (int)items : 1;
         const int64_t flat = mnw::reg_max_items_per_block();
         int64_t lim = grid < flat ? grid : flat;
         if (c->big_blocks) {
-            lim = 2 * (int64_t)grid;
-            if (lim > mnw::reg_max_items_per_big_block()) lim = mnw::reg_max_items_per_big_block();
+            const int nsw = mnw::encode_reg_f32_sweepers();
+            const int gi = full - nsw < items ? full - nsw : (int)items;          // item workgroups if the sweepers come out of the full grid
+            const int64_t fsw = c->float_flat_items < flat ? c->float_flat_items : flat;
+            if (max_ni > (gi < fsw ? gi : fsw) && gi >= 1 && max_ni <= 2 * (int64_t)gi) {
+                nsw_f = nsw; flat_f = (int)(gi < fsw ? gi : fsw); grid = gi + nsw; lim = 2 * (int64_t)gi;
+            } else {
+                lim = 2 * (int64_t)grid;
+                if (lim > mnw::reg_max_items_per_big_block()) lim = mnw::reg_max_items_per_big_block();
+            }
         }
         if (max_ni > lim) fl = false;
     }
@@ -963,7 +976,7 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
     }
     if (!in) items_i = 0;
     if (!fl && !in) return MNW_OK;
-    const bool unweighted = max_ni > grid;
+    const bool unweighted = max_ni > grid - nsw_f;
     if (fl) {
         items = 0;
         for (int k = 0; k < nfloat; ++k) {
@@ -971,7 +984,7 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
             sl->h_jobs[k].tile0 = items;          // first ITEM of the job in this launch
             sl->h_jobs[k].grp0 = groups;          // ... and its group records: R x R of them (R copies of R records), large blocks only
             items += ni;
-            if (ni > mnw::reg_max_items_per_block()) {
+            if (nsw_f == 0 && ni > mnw::reg_max_items_per_block()) {
                 const int64_t R = (ni + mnw::reg_group_items() - 1) / mnw::reg_group_items();
                 groups += R * R;
             }
@@ -982,7 +995,8 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         int64_t t = 0;
         for (int k = nfloat; k < nslot_all; ++k) { sl->h_jobs[k].tile0 = t; t += (sl->h_jobs[k].n + item_i - 1) / item_i; }
     }
-    const size_t need = (size_t)(items + groups + items_i + (nsw_i ? nslot_all - nfloat : 0)) * mnw::item_rec_bytes();      // (+ one descriptor record per int job)
+    const int64_t fdrecs = nsw_f ? nfloat : 0;            // one descriptor record per float job, behind the group records
+    const size_t need = (size_t)(items + groups + fdrecs + items_i + (nsw_i ? nslot_all - nfloat : 0)) * mnw::item_rec_bytes();      // (+ one descriptor record per int job)
     if (need > c->cap_recs) {
         // (re)allocation happens between batches only: the previous batch has been finished by then
         if (c->d_recs) { HIPCHK(c, hipStreamSynchronize(s)); HIPCHK(c, hipFree(c->d_recs)); }
@@ -1038,14 +1052,14 @@ int launch_encode_reg(mnw_ctx* c, JobSlot* sl, hipStream_t s, int nfloat, int ns
         mnw::launch_encode_reg_f32(s, grid, sl->d_jobs, nfloat, items, sl->d_itemjob, c->d_recs,
                                    (uint8_t*)c->d_recs + (size_t)items * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl), sl->d_hsync,
                                    sl->d_meta, (grid == c->cus * 4 && !unweighted && c->reg_weighted) ? 1 + c->reg_round_table : 0, c->reg_drop_item, any_xform,
-                                   max_ni > mnw::reg_max_items_per_block() ? 1 : 0);
+                                   max_ni > flat_f ? 1 : 0, (uint8_t*)c->d_recs + (size_t)(items + groups) * mnw::item_rec_bytes(), nsw_f, flat_f);
     }
     if (in && items_i > 0) {
         ScopedTimer t(c, s, MNW_K_ENCODE_REG_I64);
         mnw::launch_encode_reg_i64(s, grid_i, sl->d_jobs + nfloat, nslot_all - nfloat, items_i, sl->d_itemjob + items_pad,
-                                   (uint8_t*)c->d_recs + (size_t)(items + groups) * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl),
+                                   (uint8_t*)c->d_recs + (size_t)(items + groups + fdrecs) * mnw::item_rec_bytes(), c->reg_gen, abort_ptr(sl),
                                    sl->d_hsync, sl->d_meta + nfloat, (grid_i == c->cus * 4 && c->reg_weighted && nsw_i == 0) ? 1 + c->reg_round_table : 0, c->reg_drop_item,
-                                   (uint8_t*)c->d_recs + (size_t)(items + groups + items_i) * mnw::item_rec_bytes(), nsw_i, flat_i);
+                                   (uint8_t*)c->d_recs + (size_t)(items + groups + fdrecs + items_i) * mnw::item_rec_bytes(), nsw_i, flat_i);
     }
     HIPCHK(c, hipGetLastError());
     *did_float = fl; *did_int = in;
@@ -1240,6 +1254,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "vec3_fused")) { c->vec3_fused = value != 0; return MNW_OK; }
     if (!strcmp(name, "vec3_deep")) { c->vec3_deep = value < 3 ? 3 : value > 5 ? 5 : (int)value; c->reg_vec3_blocks_per_cu = 0; return MNW_OK; }
     if (!strcmp(name, "vec3_round_table")) { c->vec3_round_table = (int)value; return MNW_OK; }
+    if (!strcmp(name, "float_flat_items")) { if (value < 1) return MNW_E_ARG; c->float_flat_items = (int)(value > 512 ? 512 : value); return MNW_OK; }
     if (!strcmp(name, "int_flat_items")) { if (value < 1) return MNW_E_ARG; c->int_flat_items = (int)(value > 512 ? 512 : value); return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_tiles")) { if (value < 1 || value > 1024) return MNW_E_ARG; c->vec3_unpack_tiles = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_x_order")) { if (value < 0 || value > 2) return MNW_E_ARG; c->vec3_x_order = (int)value; return MNW_OK; }

@@ -1242,9 +1242,16 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
                                                                  ItemRec* __restrict__ recs, ItemRec* __restrict__ grecs,
                                                                  uint32_t gen, uint32_t* __restrict__ abort_flag,
                                                                  uint32_t* __restrict__ abort_host,
-                                                                 Meta* __restrict__ meta, int weighted, int64_t test_drop_item) {
+                                                                 Meta* __restrict__ meta, int weighted, int64_t test_drop_item,
+                                                                 ItemRec* __restrict__ drecs, int n_sweepers, int flat_lim) {
     // (test_drop_item: test hook, normally -1 -- the record of that item is never published, so its block can
     // never complete and the launch has to take its bounded-wait exit)
+    // BIG, n_sweepers > 0 (round 3): blocks of more than flat_lim items -- up to 2 G items, G = the workgroups that hold items --
+    // get their descriptor from one of the last n_sweepers workgroups of the grid, which hold no items: sweeper s takes the large
+    // jobs j = s (mod n_sweepers) in order, waits for the block's last record, folds all of them and publishes ONE descriptor record
+    // (drecs[j]: the two halves of the descriptor word, tagged); the item workgroups poll that instead of sweeping or doing group
+    // duty.  k_encode_reg_i64's header has the deadlock argument.  n_sweepers == 0: the two-level sweep below, which a block of
+    // 2 x gridDim.x items (2^24 elements on a whole MI355X) needs because it leaves no workgroup over.
     __shared__ __attribute__((aligned(16))) uint32_t lds[kBufR];
     __shared__ float red[4][kThreadsR / 64];
     __shared__ int redbad[kThreadsR / 64];
@@ -1297,7 +1304,88 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
     // each).  No two partial rounds are adjacent, so two consecutive items of a workgroup are at least a
     // whole grid apart and the header's argument holds unchanged.  (Handing the items out with a counter
     // instead puts a returning atomic on wave 0's path every trip and measured 15 % slower overall.)
-    const int unit = weighted ? (int)gridDim.x / 4 : (int)gridDim.x;
+    const int G = (int)gridDim.x - (BIG ? n_sweepers : 0);          // workgroups that hold items
+    if (BIG && (int)blockIdx.x >= G) {
+        // ---- sweeper: the descriptors of the large blocks j = s (mod n_sweepers), in job order
+        const int s_id = (int)blockIdx.x - G;
+        int seen = 0;                                    // large jobs before j0 (uniform)
+        if (tid == 0) shared_slot = 0;                   // here: "gave up"
+        lds_barrier();
+        for (int j0 = 0; j0 < njobs; j0 += kThreadsR) {
+            const int jt = j0 + tid;
+            reinterpret_cast<uint8_t*>(lds)[tid] = (jt < njobs && items_of(jobs[jt].n) > flat_lim) ? 1 : 0;
+            lds_barrier();
+            for (int q = 0; q < kThreadsR && j0 + q < njobs; ++q) {
+                if (!reinterpret_cast<const uint8_t*>(lds)[q]) continue;
+                const bool mine = seen % n_sweepers == s_id;
+                ++seen;
+                if (!mine) continue;
+                const int j = j0 + q;
+                const int T = (int)items_of(jobs[j].n);
+                const ItemRec* r0 = recs + jobs[j].tile0;
+                uint32_t spins = 0;
+                const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                // a hint that the block is (nearly) complete: its last record
+                for (;;) {
+                    uint64_t w[4];
+                    load_rec_sc1(r0 + (T - 1), w);
+                    if (((uint32_t)(w[3] >> 32) & ~kRecBad) == gen) break;
+                    if (poll_abort(spins, t_start, abort_flag, abort_host)) { if (lane_id() == 0) shared_slot = 1; break; }
+                }
+                lds_barrier();
+                if (shared_slot) return;
+                for (;;) {
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    uint32_t bad = 0, missing = 0;
+                    for (int r = tid; r < T; r += kThreadsR) {
+                        uint64_t w4[4];
+                        load_rec_sc1(r0 + r, w4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t tag = (uint32_t)(w4[k] >> 32);
+                            missing |= (tag & ~kRecBad) != gen;
+                            bad |= tag & kRecBad;
+                            const uint32_t val = (uint32_t)w4[k];
+                            v[k] = val > v[k] ? val : v[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = wave_max_dpp(v[k]);
+                    const uint32_t fl = (__any(missing) ? 1u : 0u) | (__any(bad) ? 2u : 0u);
+                    if (lane_id() == 0) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) swv[k][wave_id()] = v[k];
+                        swf[wave_id()] = fl;
+                    }
+                    lds_barrier();
+                    uint32_t v0 = swv[0][0], v1 = swv[1][0], v2 = swv[2][0], v3 = swv[3][0], flw = swf[0];
+#pragma unroll
+                    for (int w = 1; w < kW; ++w) {
+                        v0 = max(v0, swv[0][w]); v1 = max(v1, swv[1][w]); v2 = max(v2, swv[2][w]); v3 = max(v3, swv[3][w]);
+                        flw |= swf[w];
+                    }
+                    if (!(flw & 1u)) {
+                        if (wave_id() == 0) {
+                            const DevJob jb = jobs[j];
+                            const uint64_t g = desc_from_sweep_f32(jb, j, v0, v1, v2, v3, (flw & 2u) != 0, meta, true);
+                            // the record: {descriptor word low, high, 0, 0}, each word tagged
+                            const int l = lane_id();
+                            const uint32_t val = l == 0 ? (uint32_t)g : l == 1 ? (uint32_t)(g >> 32) : 0u;
+                            if (l < 4) __hip_atomic_store(&drecs[j].g[l], (uint64_t)val | ((uint64_t)gen << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        lds_barrier();                   // (swv / swf are free again)
+                        break;
+                    }
+                    if (wave_id() == 0 && poll_abort(spins, t_start, abort_flag, abort_host) && lane_id() == 0) shared_slot = 1;
+                    lds_barrier();
+                    if (shared_slot) return;
+                }
+            }
+            lds_barrier();                               // (the flags are rewritten by the next stretch)
+        }
+        return;
+    }
+    const int unit = weighted ? G / 4 : G;
     int round = 0;
     int64_t round_base = 0;
     auto next_item = [&]() -> int64_t {           // the workgroup's item after the one in (round, round_base)
@@ -1345,9 +1433,12 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
             const ItemRec* r0 = recs + pjb.tile0;
             // (a large block: the records of the parked item's GROUP, lanes 0..63 -- see group_duty_f32)
             int nload = pitems, first = 0;
-            if (BIG && pitems > kMaxSweep) {
-                first = (int)(pit - pjb.tile0) / kGroupItems * kGroupItems;
-                nload = pitems - first < kGroupItems ? pitems - first : kGroupItems;
+            if (BIG && pitems > flat_lim) {
+                if (n_sweepers > 0) nload = 0;                       // (its descriptor comes from a sweeper: nothing to fold)
+                else {
+                    first = (int)(pit - pjb.tile0) / kGroupItems * kGroupItems;
+                    nload = pitems - first < kGroupItems ? pitems - first : kGroupItems;
+                }
             }
             // Two 16-byte agent-scope loads per record, not four 8-byte ones: half as many requests on the record lines, which
             // every workgroup of a block reads, and requests on one line are served one after the other (measured in one run,
@@ -1436,7 +1527,7 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
                     const uint32_t val = (uint32_t)sw[k];
                     v[k] = val > v[k] ? val : v[k];
                 }
-                if (h == 1 || pitems <= kThreadsR || (BIG && pitems > kMaxSweep)) break;
+                if (h == 1 || pitems <= kThreadsR || (BIG && pitems > flat_lim)) break;
                 const ItemRec* r1 = recs + pjb.tile0 + kThreadsR;
                 const uint64_t neutral = (uint64_t)gen << 32;
                 if (tid + kThreadsR < pitems) load_rec_sc1(r1 + tid, sw);
@@ -1485,11 +1576,23 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
                     fl |= swf[w];
                 }
                 uint64_t g;
-                if (BIG && pitems > kMaxSweep) {
+                if (BIG && pitems > flat_lim) {
                     // a large block.  Its descriptor may be known from the trip before (the workgroup's previous item was in
-                    // the same block); else: the current item's group first if that is part of the block, then the sweep
+                    // the same block); else: from a sweeper's record, or (no sweepers) the current item's group first if that is
+                    // part of the block, then the sweep
                     if (pj == desc_job) g = desc_word;
-                    else {
+                    else if (n_sweepers > 0) {
+                        uint32_t spins = 0;
+                        const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+                        g = 0;
+                        for (;;) {
+                            uint64_t w[4];
+                            load_rec_sc1(drecs + pj, w);
+                            if ((uint32_t)(w[0] >> 32) == gen && (uint32_t)(w[1] >> 32) == gen) { g = (uint64_t)(uint32_t)w[0] | ((uint64_t)(uint32_t)w[1] << 32); break; }
+                            if (poll_abort(spins, t_start, abort_flag, abort_host)) break;
+                        }
+                        desc_job = pj; desc_word = g;
+                    } else {
                         // the group of the parked item: from the records loaded at the start of the trip, if they were all there
                         bool ok2 = true;
                         if (fl & 1u) ok2 = group_duty_f32(jobs, pj, pit, recs, grecs, gen, abort_flag, abort_host);
@@ -2492,10 +2595,13 @@ void launch_encode_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, c
 size_t job_sync_bytes() { return sizeof(JobSync); }
 void launch_encode_reg_f32(hipStream_t s, int grid, const DevJob* jobs, int njobs, int64_t items, const int* item_job, void* recs,
                            void* grecs, uint32_t gen, uint32_t* abort_flag, uint32_t* abort_host, Meta* meta, int weighted,
-                           int64_t test_drop_item, int any_xform, int big) {
-    const int w = (weighted > 0 && weighted <= kRoundTables && grid % 4 == 0) ? weighted : 0;     // 1 + the round table
+                           int64_t test_drop_item, int any_xform, int big, void* drecs = nullptr, int n_sweepers = 0, int flat_lim = kMaxSweep) {
+    // grid: the item workgroups AND the sweepers (the last n_sweepers, big launches only; flat_lim: blocks of more items are "large")
+    if (!big) n_sweepers = 0;
+    const int w = (weighted > 0 && weighted <= kRoundTables && (grid - n_sweepers) % 4 == 0) ? weighted : 0;     // 1 + the round table
 #define MNW_LAUNCH_REG(XF, BIG) hipLaunchKernelGGL((k_encode_reg_f32<XF, BIG>), dim3(grid), dim3(kThreadsR), 0, s, jobs, njobs, items, item_job, \
-                                                   (ItemRec*)recs, (ItemRec*)grecs, gen, abort_flag, abort_host, meta, w, test_drop_item)
+                                                   (ItemRec*)recs, (ItemRec*)grecs, gen, abort_flag, abort_host, meta, w, test_drop_item, \
+                                                   (ItemRec*)drecs, n_sweepers, flat_lim)
     if (any_xform) { if (big) MNW_LAUNCH_REG(true, true); else MNW_LAUNCH_REG(true, false); }
     else { if (big) MNW_LAUNCH_REG(false, true); else MNW_LAUNCH_REG(false, false); }
 #undef MNW_LAUNCH_REG
@@ -2509,6 +2615,7 @@ void launch_encode_reg_i64(hipStream_t s, int grid, const DevJob* jobs, int njob
                        (ItemRec*)drecs, n_sweepers, flat_lim);
 }
 int encode_reg_i64_sweepers() { return 8; }
+int encode_reg_f32_sweepers() { return 8; }
 int64_t reg_item_elems_i64() { return kItemI; }
 int encode_reg_i64_blocks_per_cu() {
     int n = 0;

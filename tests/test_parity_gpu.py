@@ -786,10 +786,11 @@ def test_single_read_falls_back_for_blocks_beyond_the_chip(mnw, oracle, torch_mo
         assert kt["k_pack_f32"]["launches"] >= 1 and not kt.get("k_encode_reg_f32", {"launches": 0})["launches"]
 
 
-@pytest.mark.parametrize("shape", ["2p24", "mixed", "one_and_a_half_grids", "wrapped_and_constant"])
+@pytest.mark.parametrize("shape", ["2p24", "mixed", "one_and_a_half_grids", "wrapped_and_constant", "sweepers", "sweepers_from_257_items"])
 def test_single_read_large_blocks_bit_exact(mnw, oracle, torch_mod, shape):
-    """Blocks of more than 2^22 elements, up to twice the grid's items, are read once too (two-level record sweep,
-    k_encode_reg_f32<.., BIG>): same (min, bits) and bytes as the oracle; the launch that ran is the single-read one."""
+    """Blocks of more than 2^22 elements, up to twice the grid's items, are read once too (k_encode_reg_f32<.., BIG>: descriptor
+    records from sweeper workgroups when every block has at most 2 x (grid - 8) items -- the last three shapes --, the two-level
+    record sweep otherwise): same (min, bits) and bytes as the oracle; the launch that ran is the single-read one."""
     rng = np.random.default_rng(26)
 
     def col(n, c=125.0, sg=20.0):
@@ -803,6 +804,10 @@ def test_single_read_large_blocks_bit_exact(mnw, oracle, torch_mod, shape):
         xs = [col(2**20), col(2**23 + 12345), col(77), col(2**22 + 8192 + 3, 249.9, 0.5), col(2**20 + 1), col(2**24), col(3 * 8192)]
     elif shape == "one_and_a_half_grids":
         xs = [col(1536 * 8192 + 17), col(1025 * 8192), col(513 * 8192 - 1), col(2047 * 8192 + 1)]
+    elif shape in ("sweepers", "sweepers_from_257_items"):
+        # the largest block the sweepers take on an MI355X (2 x 1,016 items), one and a half grids, just above the flat sweep's 512
+        # items, small blocks in between, a 300-item block (flat, or a sweeper's with float_flat_items = 256)
+        xs = [col(2032 * 8192), col(1000), col(1536 * 8192 + 17), col(513 * 8192 - 1, 249.9, 0.5), col(2**20), col(300 * 8192 - 7), col(1017 * 8192)]
     else:
         a = col(2**23 + 999, 0.1, 0.3)                                              # ring wrapped: pmin != 0
         b = np.full(2**23 + 4096, 25.0, dtype=np.float32)                           # constant: bits == 0
@@ -810,6 +815,8 @@ def test_single_read_large_blocks_bit_exact(mnw, oracle, torch_mod, shape):
         xs = [a, b, c]
     with mnw.Context(0) as c2:
         c2.timing_enable(True)
+        if shape == "sweepers_from_257_items":
+            c2.set_option("float_flat_items", 256)
         _encode_and_compare(mnw, oracle, torch_mod, c2, xs, reps=2)
         kt = c2.timing_get()
         assert kt["k_encode_reg_f32"]["launches"] == 2, kt
@@ -819,14 +826,15 @@ def test_single_read_large_blocks_bit_exact(mnw, oracle, torch_mod, shape):
         assert cn["single_read_batches"] == 2 and cn["single_read_aborts"] == 0 and cn["two_pass_batches"] == 0
 
 
-def test_single_read_large_block_abort_and_fallback(mnw, oracle, torch_mod):
-    """The bounded wait of the two-level sweep: a dropped item record in a 2^24-element block makes the launch give up
-    and the host rerun the batch through reduce + pack."""
+@pytest.mark.parametrize("n", [2**24, 2**23 + 5])
+def test_single_read_large_block_abort_and_fallback(mnw, oracle, torch_mod, n):
+    """The bounded wait of the two-level sweep (2^24 elements) and of the sweeper workgroups (2^23 + 5): a dropped item record
+    makes the launch give up and the host rerun the batch through reduce + pack."""
     rng = np.random.default_rng(27)
-    xs = [np.mod(125 + 20 * rng.standard_normal(2**24), 250.0).astype(np.float32)]
+    xs = [np.mod(125 + 20 * rng.standard_normal(n), 250.0).astype(np.float32)]
     with mnw.Context(0) as c2:
         c2.set_option("single_read_backoff", 0)           # (this test wants every batch to try the single-read kernel)
-        c2.set_option("reg_test_drop_item", 1500)
+        c2.set_option("reg_test_drop_item", 1500 if n == 2**24 else 700)
         c2.timing_enable(True)
         _encode_and_compare(mnw, oracle, torch_mod, c2, xs)
         kt = c2.timing_get()
