@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
             // (lane-specific addresses are built from an opaque lane number inside the trip: hoisted out of the loop they are kept,
             // and spilled, across everything else)
             const int lq = opaque_tid() & 63;
-            uint32_t bw = 0, full = 0, rem = 0;
+            uint32_t bw = 0, full = 0, rem = 0, lpad = 0;
             int64_t byte0 = 0;
             uint32_t* plane = lds + (wv < 3 ? wv : 0) * kVPlane;
             __amdgpu_buffer_rsrc_t dst_r = v3_rsrc(nullptr, 0);
@@ -814,7 +814,13 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
 #pragma unroll
                         for (int i = 0; i < kGroup; ++i) if (e0 + i >= jp.n) qq[i] = 0;
                     }
-                    pack_group32_switch(qq, bw, plane + lq * bw);          // (every lane holds its group: the plane can be overwritten)
+                    // (every lane holds its group: the plane can be overwritten.)  A lane's bw words start bw dwords after its
+                    // neighbour's; for bw = 8, 16, 24, 32 the 16-byte writes of eight neighbouring lanes then fall on two or four
+                    // bank groups instead of eight (LDS bank conflicts: 56 % of this kernel's LDS cycles by the counters, positions
+                    // being 16 and 17 bits wide): those widths get one empty 16-byte unit per lane (stride bw + 4: an odd number of
+                    // units), which the read-out below skips
+                    lpad = (bw & 7u) == 0 ? 4u : 0u;
+                    pack_group32_switch(qq, bw, plane + lq * (bw + lpad));
                     byte0 = (int64_t)ot * (kVTile / 8) * bw;
                     const int64_t nbytes = array_bytes(bw, jp.n);
                     int64_t nbytes_t = (int64_t)(kVTile / 8) * bw;
@@ -825,14 +831,19 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // 16-byte unit c of the stream sits at unit c + c / (bw / 4) of the plane when the lanes' outputs are padded
+            const uint32_t m_units = lpad ? 0xffffffffu / (bw >> 2) + 1u : 0u;          // (scalar; c / d == umulhi(c, m) for c < 2^16)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint32_t c = (uint32_t)lq + 64u * i;
-                const u32x4 ch = *reinterpret_cast<const u32x4*>(plane + 4 * c);
+                const uint32_t pc = c + __umulhi(c, m_units);
+                const u32x4 ch = *reinterpret_cast<const u32x4*>(plane + 4 * (pc < (uint32_t)(kVPlane / 4) ? pc : 0u));
                 __builtin_amdgcn_raw_buffer_store_b128(ch, dst_r, (int)(c < full ? 16u * c : kV3Oob), 0, 0);
             }
             {
-                const uint32_t wd = plane[4 * full + ((uint32_t)lq >> 2)];
+                const uint32_t tu = full + ((uint32_t)lq >> 4);                            // the unit that holds the lane's tail byte
+                const uint32_t pw = 4 * (tu + __umulhi(tu, m_units)) + (((uint32_t)lq >> 2) & 3u);
+                const uint32_t wd = plane[pw < (uint32_t)kVPlane ? pw : 0u];
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(wd >> (8 * (lq & 3))), dst_r, (int)((uint32_t)lq < rem ? 16u * full + (uint32_t)lq : kV3Oob), 0, 0);
             }
         }
