@@ -56,6 +56,7 @@ int64_t vec3_tiles(int64_t, int64_t);
 int64_t vec3_reg_recs(int64_t, int64_t);
 int64_t vec3_reg_max_tiles_per_block();
 int vec3_reg_sweepers();
+void vec3_reg_set_sweepers(int);
 bool vec3_reg_geometry_ok(int64_t, int64_t);
 int encode_reg_vec3_blocks_per_cu(int);
 void launch_encode_reg_vec3(hipStream_t, int, const float*, int64_t, int64_t, const DevJob*, void*, uint32_t, uint32_t*, uint32_t*, Meta*, int64_t, int, int);
@@ -1256,6 +1257,7 @@ int mnw_set_option(mnw_ctx* c, const char* name, int64_t value) {
     if (!strcmp(name, "vec3_round_table")) { c->vec3_round_table = (int)value; return MNW_OK; }
     if (!strcmp(name, "float_flat_items")) { if (value < 1) return MNW_E_ARG; c->float_flat_items = (int)(value > 512 ? 512 : value); return MNW_OK; }
     if (!strcmp(name, "int_flat_items")) { if (value < 1) return MNW_E_ARG; c->int_flat_items = (int)(value > 512 ? 512 : value); return MNW_OK; }
+    if (!strcmp(name, "vec3_sweepers")) { mnw::vec3_reg_set_sweepers((int)value); return MNW_OK; }      // (process-wide)
     if (!strcmp(name, "vec3_unpack_tiles")) { if (value < 1 || value > 1024) return MNW_E_ARG; c->vec3_unpack_tiles = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_x_order")) { if (value < 0 || value > 2) return MNW_E_ARG; c->vec3_x_order = (int)value; return MNW_OK; }
     if (!strcmp(name, "vec3_unpack_db")) { c->vec3_unpack_db = value != 0; return MNW_OK; }

@@ -536,8 +536,11 @@ struct Vec3JobPar {
 };
 
 // a block's descriptor from its swept statistics (max form) -- the decisions of make_desc_f32 on integers
-__device__ __forceinline__ Desc v3_desc(const Vec3JobPar& jp, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, bool bad) {
+// (wraps: the block is the ring's second arc -- values below the arc's start exist and bound() lifts them by `pixels`; in the other
+// two cases every value is at or above the block minimum and the re-basing needs no wrap)
+__device__ __forceinline__ Desc v3_desc(const Vec3JobPar& jp, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, bool bad, bool& wraps) {
     Desc d = {0, 0, 0, 0, 0};
+    wraps = false;
     const int64_t mx0 = v3_dec_max(w0), mn0 = v3_dec_min(w1);
     const uint32_t umx = w2, umn = ~w3;
     // (a quotient beyond int32 saturates the conversion: INT32_MAX >= pixels and INT32_MIN < 0 send the block to the exact path too)
@@ -547,7 +550,7 @@ __device__ __forceinline__ Desc v3_desc(const Vec3JobPar& jp, uint32_t w0, uint3
     const bool has_lo = (int32_t)umx < 0, has_hi = (int32_t)umn >= 0;
     const int64_t mxlo = (int64_t)(uint32_t)(umx + (uint32_t)h), mnhi = (int64_t)(uint32_t)(umn + (uint32_t)h);
     if (mx0 - mn0 + 1 <= h) { d.pmin = mn0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
-    else if (has_lo && has_hi && (mxlo + jp.pixels) - mnhi + 1 <= h) { d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jp.pixels - mnhi); }
+    else if (has_lo && has_hi && (mxlo + jp.pixels) - mnhi + 1 <= h) { d.pmin = mnhi; d.imin = mnhi; maxdelta = (uint64_t)(mxlo + jp.pixels - mnhi); wraps = true; }
     else { d.pmin = 0; d.imin = mn0; maxdelta = (uint64_t)(mx0 - mn0); }
     d.bits = precision_needed(maxdelta);
     d.nbytes = d.bits == 0 ? 0 : array_bytes(d.bits, jp.n);
@@ -672,12 +675,13 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
                         uint32_t w4[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) w4[j] = max(max(red[4 * k + j][0], red[4 * k + j][1]), max(red[4 * k + j][2], red[4 * k + j][3]));
-                        const Desc d = v3_desc(jpar[k], w4[0], w4[1], w4[2], w4[3], ((flags >> k) & 1u) != 0);
+                        bool wraps;
+                        const Desc d = v3_desc(jpar[k], w4[0], w4[1], w4[2], w4[3], ((flags >> k) & 1u) != 0, wraps);
                         const int64_t j = (int64_t)k * s3 + sc_;
                         Meta m = {d.imin, (int64_t)d.bits, d.nbytes, (int64_t)d.status};
                         meta[j] = m;
                         const uint32_t code = d.status == 0 ? 0u : d.status == (int)kNeedsExact ? 1u : d.status == -5 ? 2u : 3u;
-                        const uint32_t info = (uint32_t)d.bits | ((d.pmin == d.imin) ? 0x80u : 0u) | (code << 8);
+                        const uint32_t info = (uint32_t)d.bits | (wraps ? 0x80u : 0u) | (code << 8);
                         const u32x4 rec = {(uint32_t)(int32_t)d.imin, gen, info, gen};
                         __builtin_amdgcn_raw_buffer_store_b128(rec, rec_r, (int)(desc_off0 + (uint32_t)j * 16u), 0, 16);
                     }
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256, DEPTH == 3 ? 4 : 3) void k_encode_reg_vec3(Vec
                         if (poll_abort(spins, t_start, ra.abort_flag, ra.abort_host)) { if (l == 0) abort_s = 1; info = 0x100u; break; }
                     }
                 }
-                // info: bits 0..6 width, bit 7 pmin == imin, bits 8.. status code (0 ok)
+                // info: bits 0..6 width, bit 7 the block is the ring's second arc (re-basing wraps), bits 8.. status code (0 ok)
                 imin = (uint32_t)__builtin_amdgcn_readfirstlane((int)imin); info = (uint32_t)__builtin_amdgcn_readfirstlane((int)info);
                 if (wv == 0) { MNW_V3_TRACE(2 * total + osc * T + ot) }
                 MNW_STAMP(0)      // the descriptor is there (wait for its load, or poll)
@@ -1286,7 +1290,9 @@ int64_t vec3_reg_recs(int64_t n_file, int64_t sub_cells) {
     const int64_t s3 = sub_cells * sub_cells * sub_cells, T = (g.n_sub3 + kVTile - 1) / kVTile;
     return 3 * s3 * T + (3 * s3 + 1) / 2;
 }
-int vec3_reg_sweepers() { return 8; }                                      // workgroups of the grid that hold no items
+static int g_v3_sweepers = 8;
+int vec3_reg_sweepers() { return g_v3_sweepers; }                          // workgroups of the grid that hold no items
+void vec3_reg_set_sweepers(int n) { g_v3_sweepers = n < 1 ? 1 : n > 64 ? 64 : n; }   // (tuning knob: option vec3_sweepers)
 int64_t vec3_reg_max_tiles_per_block() { return 1ll << 20; }               // (the sweep takes any T; what bounds T is the resident grid)
 // geometries k_encode_reg_vec3 takes: its multiply-high divisions need 8 <= n_sub < 512, n_sub a multiple of four, its grid
 // offsets a sub-cell's span of the grid below 2^32 bytes, its record offsets fewer than 2^26 records
