@@ -615,19 +615,26 @@ __device__ __forceinline__ void pack_group64_lds(const uint32_t* __restrict__ in
 
 // coalesced write-out of one tile's packed words from LDS: 16-byte chunks, then the ragged tail of
 // the block's last tile byte-wise (ArrayBytes is a byte count, bit.go:23-25; pad bits are zero)
+// units_per_lane > 0: every lane's words are followed by one empty 16-byte unit in LDS (pack_stride), unit c of the stream then
+// sits at unit c + c / units_per_lane (units_per_lane = b / 4 is wave-uniform; c < 2^16)
 template <int NT = kThreads>
 __device__ __forceinline__ void store_tile(const uint32_t* __restrict__ lds_out, uint8_t* __restrict__ dst,
-                                           int64_t tile_byte0, int64_t tile_bytes, int tid = threadIdx.x) {
+                                           int64_t tile_byte0, int64_t tile_bytes, int tid = threadIdx.x, uint32_t units_per_lane = 0) {
     const int full = (int)(tile_bytes >> 4);
+    const uint32_t m = units_per_lane ? 0xffffffffu / units_per_lane + 1u : 0u;
     for (int c = tid; c < full; c += NT)
-        stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(lds_out + 4 * c));
+        stg<u32x4>(dst + tile_byte0 + 16 * (int64_t)c, *reinterpret_cast<const u32x4*>(lds_out + 4 * ((uint32_t)c + __umulhi((uint32_t)c, m))));
     const int rem = (int)(tile_bytes & 15);
     if (tid < rem) {
         const int k = tid;
-        const uint32_t w = lds_out[4 * full + (k >> 2)];
+        const uint32_t w = lds_out[4 * ((uint32_t)full + __umulhi((uint32_t)full, m)) + (k >> 2)];
         stg<uint8_t>(dst + tile_byte0 + 16 * (int64_t)full + k, (uint8_t)(w >> (8 * (k & 3))));
     }
 }
+// Dwords between the packed outputs of neighbouring lanes: b, but for b = 8, 16, 24, 32 one 16-byte unit more -- with a stride of 8,
+// 16, 24 or 32 dwords the 16-byte writes of eight neighbouring lanes fall on two or four LDS bank groups instead of eight (measured
+// on k_encode_reg_vec3: bank conflicts were 56 % of its LDS cycles with 16-bit blocks); b + 4 is an odd number of units.
+__device__ __forceinline__ uint32_t pack_stride(uint32_t b) { return b + ((b & 7u) == 0 ? 4u : 0u); }
 
 // the lane's index in the workgroup as a value the compiler cannot see through: address arithmetic built
 // on it inside a loop is redone there (two or three instructions) instead of being hoisted out of the loop
@@ -820,13 +827,13 @@ __device__ __forceinline__ bool pack_range_f32(uint32_t* __restrict__ lds, uint6
                 }
                 lds_barrier();                      // everyone holds its group: the stage can be overwritten
                 MNW_STAMP(3)  // transposed LDS read + barrier
-                pack_group32(g, b, lds + tid * b);
+                pack_group32(g, b, lds + tid * pack_stride(b));
                 lds_barrier();
                 MNW_STAMP(4)  // pack + barrier
                 const int64_t tile_byte0 = base / 8 * b;
                 int64_t tile_bytes = (int64_t)kTile / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes, threadIdx.x, (b & 7u) == 0 ? b >> 2 : 0u);
                 lds_barrier();                      // write-out done before the next tile is staged
                 MNW_STAMP(5)  // LDS read-out + global stores issued + barrier
             }
@@ -1679,13 +1686,13 @@ __global__ __launch_bounds__(kThreadsR, XF ? MNW_XF_WGS : 4) void k_encode_reg_f
                     for (int i = 0; i < kGroup; ++i)
                         if (e0 + i >= pjb.n) q[i] = 0;
                 }
-                pack_group32_switch(q, b, lds + tid * b);
+                pack_group32_switch(q, b, lds + tid * pack_stride(b));
                 lds_barrier();
                 MNW_STAMP(3)      // re-base + pack + barrier
                 const int64_t tile_byte0 = pbase / 8 * b;
                 int64_t tile_bytes = (int64_t)kItem / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid());
+                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid(), (b & 7u) == 0 ? b >> 2 : 0u);
             }
             lds_barrier();                                     // the LDS buffer is free again
             MNW_STAMP(4)      // stores issued + barrier
@@ -2103,12 +2110,12 @@ __global__ __launch_bounds__(kThreadsR, 4) void k_encode_reg_i64(const DevJob* _
             lds_barrier();                                         // every packing lane holds its group: the stage can be overwritten
             if (ok) {
                 const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(d.bits);
-                if (tid < kItemI / kGroup) pack_group32_switch(q, b, lds + tid * b);
+                if (tid < kItemI / kGroup) pack_group32_switch(q, b, lds + tid * pack_stride(b));
                 lds_barrier();
                 const int64_t tile_byte0 = pbase / 8 * b;
                 int64_t tile_bytes = (int64_t)kItemI / 8 * b;
                 if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid());
+                store_tile<kThreadsR>(lds, (uint8_t*)pjb.dst, tile_byte0, tile_bytes, opaque_tid(), (b & 7u) == 0 ? b >> 2 : 0u);
             }
             lds_barrier();
         }
@@ -2209,12 +2216,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_pack_i64(const DevJob* __restri
                         g[4 * k] = r.x; g[4 * k + 1] = r.y; g[4 * k + 2] = r.z; g[4 * k + 3] = r.w;
                     }
                     lds_barrier();
-                    pack_group32(g, b, lds + tid * b);
+                    pack_group32(g, b, lds + tid * pack_stride(b));
                     lds_barrier();
                     const int64_t tile_byte0 = base / 8 * b;
                     int64_t tile_bytes = (int64_t)kTile / 8 * b;
                     if (tile_byte0 + tile_bytes > d.nbytes) tile_bytes = d.nbytes - tile_byte0;
-                    store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes);
+                    store_tile(lds, (uint8_t*)jb.dst, tile_byte0, tile_bytes, threadIdx.x, (b & 7u) == 0 ? b >> 2 : 0u);
                     lds_barrier();
                 }
             } else {

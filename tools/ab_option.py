@@ -18,7 +18,8 @@ y = torch.empty_like(x)
 nblk = (N + B - 1) // B
 slot = (4 * B + 15) // 16 * 16
 packed = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
-pix = mnw.float_group_pixels(0.0, 250.0, 0.001)
+DX = float(os.environ.get("AB_DX", "0.001"))          # 0.004: 16-bit blocks
+pix = mnw.float_group_pixels(0.0, 250.0, DX)
 ctx = mnw.Context(0)
 ej = ctx.enc_batch([mnw.EncJob(x.data_ptr() + 4 * k * B, packed.data_ptr() + k * slot, min(B, N - k * B), slot, mnw.FLOAT_GROUP, 0.0, 250.0, pix, 1) for k in range(nblk)])
 torch.cuda.synchronize()
